@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-pairs/sec of full 6-level PWC-Net (qpwcnet ``build_flower``)
+inference at 256x512 fp32, batch 8 per GPU (BASELINE.json configs[1]; configs[2] = the same
+per-GPU work on 8 GPUs), synthetic frames and seeded random-init weights.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward pass of one batch already resident in HBM: encoder/decoder/flow
+estimator convolutions on PyTorch-ROCm, 5 cost volumes + 4 warps in the HIP kernels,
+6 per-level EPE reductions, and (N > 1) one RCCL all-gather of the 6-float EPE vector.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from qpwcnet_amd import dist as qdist  # noqa: E402
+from qpwcnet_amd import metrics, ops, synth  # noqa: E402
+from qpwcnet_amd.pwcnet import build_flower  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s copy-measured
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--batch", type=int, default=8, help="pairs per GPU (weak scaling)")
+    p.add_argument("--height", type=int, default=256)
+    p.add_argument("--width", type=int, default=512)
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--fused", dest="fused", action="store_true", default=False,
+                   help="fused warp+cost-volume UpFlow front end")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the host for cpu_baseline")
+    return p.parse_args()
+
+
+def cost_volume_bytes(B, H, W, C, esize=4):
+    """Algorithmic bytes of one cost-volume launch: read prv + nxt, write 81 channels
+    (B*H*W*(2C+81)*e)."""
+    return B * H * W * (2 * C + 81) * esize
+
+
+def cpu_baseline(weights, pairs_np, n_pairs, gpu_flows):
+    """The reference-algorithm CPU restatement (oracle/net_ref.py; TF2 itself cannot run
+    offline) on the host cores, on the first n_pairs of the same workload."""
+    from oracle import net_ref, torch_ref
+    n_pairs = max(1, min(n_pairs, pairs_np.shape[0]))
+    net = net_ref.RefNet(weights)
+    cores = torch.get_num_threads()
+    net(pairs_np[:1])  # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    ref = net(pairs_np[:n_pairs])
+    dt = time.perf_counter() - t0
+    epe = [float(torch_ref.epe_error(a[:n_pairs].float().cpu(), b)) for a, b in zip(gpu_flows, ref)]
+    return {
+        "value": n_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample": "{} pairs of the same batch, full 6-level net, torch-CPU op-for-op restatement "
+                  "(81x slice*mul*mean cost volume, gather warp), {:.1f} s".format(n_pairs, dt),
+    }, epe
+
+
+def main():
+    args = parse_args()
+    world, rank, local_rank = qdist.init()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus {} needs one process per GPU: launch with "
+                             "python -m torch.distributed.run --nproc-per-node {} bench.py ...".format(
+                                 args.gpus, args.gpus))
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode: pick the fastest conv solver once
+
+    hw = (args.height, args.width)
+    B = args.batch
+    weights = synth.make_weights(42, hw)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=dev, fused=args.fused)
+    pairs_np, gt_np = synth.make_frames(B, hw[0], hw[1], seed=1234 + rank)
+    pairs = torch.from_numpy(pairs_np).to(dev)
+    gt = torch.from_numpy(gt_np).to(dev)
+    shapes = [(hw[0] >> s, hw[1] >> s) for s in (5, 4, 3, 2, 1, 0)]
+    gt_pyr = metrics.multiscale_ground_truth(gt, shapes)
+
+    def forward():
+        with torch.no_grad():
+            flows = model(pairs)
+            return flows, metrics.per_level_epe(gt_pyr, flows)
+
+    # eager warm-up (MIOpen solver search, LDS attribute set-up) before any capture
+    for _ in range(3):
+        flows, epe_local = forward()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            flows, epe_local = forward()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            flows, epe_local = forward()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            e = epe_local
+        else:
+            _, e = forward()
+        return qdist.gather_epe(e, B)
+
+    for _ in range(args.warmup):
+        step()
+    qdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        per_rank, epe_mean = step()
+    qdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = qdist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # ---- live roofline of the dominant hot-path kernel: HIP events on the launch stream
+    n_prof = max(5, min(args.steps, 20))
+    with ops.kernel_timing() as kt:
+        for _ in range(n_prof):
+            forward()
+    ktimes = kt.summary()
+    lvl4 = (B, hw[0] // 2, hw[1] // 2, synth.level_channels()[-1])
+    dom_name = "warp_cost_volume" if args.fused else "cost_volume"
+    dom_key = (dom_name,) + lvl4
+    _, dom_ms = ktimes[dom_key]
+    dom_bytes = cost_volume_bytes(*lvl4)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from a separate rocprofv3 --pmc run
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name + "_L4_bytes_per_launch")
+        except Exception:
+            traffic = None
+    hot_ms = sum(n * t for (n, t) in ktimes.values()) / n_prof
+
+    result = {
+        "metric": "image-pairs/sec at 256x512 fp32",
+        "value": world * B * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: full 6-level PWC-Net (qpwcnet build_flower) inference, "
+                        "batch {} per GPU, {}x{} fp32, d=4 cost volume + WarpV2".format(B, hw[0], hw[1]),
+            "global_batch": world * B, "batch_per_gpu": B,
+            "parallelism": "dp{} (pairs sharded, RCCL all-gather of the 6 per-level EPE)".format(world),
+            "hipgraph": graph is not None, "fused_upflow": bool(args.fused),
+            "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "{} L4 {}".format(dom_name, "x".join(map(str, lvl4))),
+            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+            "launches_timed": ktimes[dom_key][0],
+        },
+        "hot_path": {
+            "ms_per_step_eager_events": hot_ms,
+            "kernels_ms": {"{} {}".format(k[0], "x".join(map(str, k[1:]))): round(t, 5)
+                           for k, (n, t) in sorted(ktimes.items())},
+        },
+        "per_level_epe_vs_ground_truth": [float(x) for x in epe_mean.cpu()],
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            base, epe_oracle = cpu_baseline(weights, pairs_np, args.cpu_pairs, flows)
+            result["cpu_baseline"] = base
+            result["per_level_epe_vs_oracle"] = epe_oracle
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        qdist.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+/* qpwc.h -- C ABI of libqpwc_hip.so: the MI355X (gfx950) hot path of qpwcnet.
+ *
+ * The reference (yycho0108/qpwcnet) has no FFI layer of its own: its boundary
+ * is the Python Keras-layer call() surface, and one level down the registered
+ * TensorFlow op of tensorflow-addons.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer;
+ *   - the caller owns all memory; kernels never allocate, free or retain;
+ *   - `out` must not overlap an input;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
+ *     default stream) and the call returns without synchronising;
+ *   - return value 0 = enqueued, negative = QPWC_E_* (nothing was enqueued);
+ *     qpwc_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef QPWC_H_
+#define QPWC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPWC_VERSION 100 /* 0.1.0 */
+
+/* layout of every image-like tensor of one call */
+#define QPWC_NHWC 0 /* 'channels_last'  (B,H,W,C) */
+#define QPWC_NCHW 1 /* 'channels_first' (B,C,H,W) */
+
+/* storage dtype; arithmetic is always fp32 */
+#define QPWC_F32 0
+#define QPWC_F16 1
+
+/* warp border semantics */
+#define QPWC_WARP_CLAMP 0  /* WarpV2: tfa dense_image_warp, clamp-to-border */
+#define QPWC_WARP_TFWARP 1 /* Warp  : qpwcnet tf_warp (truncate, clip, raw weights) */
+
+/* flo_bcast_mask bits: set = that flow dimension has extent 1 and is broadcast */
+#define QPWC_BCAST_B 1
+#define QPWC_BCAST_H 2
+#define QPWC_BCAST_W 4
+
+#define QPWC_OK 0
+#define QPWC_E_NULL (-1)     /* null pointer */
+#define QPWC_E_LAYOUT (-2)   /* 'Unsupported data format' (layers.py:19-29) */
+#define QPWC_E_DTYPE (-3)    /* unsupported dtype code */
+#define QPWC_E_SHAPE (-4)    /* non-positive extent, or H/W < 2 for clamp warp (warp.py:182-184) */
+#define QPWC_E_RANGE (-5)    /* search_range < 0 or too large */
+#define QPWC_E_MODE (-6)     /* unknown warp mode */
+#define QPWC_E_ALIAS (-7)    /* out overlaps an input */
+#define QPWC_E_LAUNCH (-8)   /* hipGetLastError() after launch; see qpwc_last_error() */
+#define QPWC_E_ALIGN (-9)    /* pointer not aligned to its element size */
+#define QPWC_E_STRIDE (-10)  /* output stride/offset cannot hold the result */
+#define QPWC_E_NODEVICE (-11)/* no HIP device / runtime error before launch */
+
+int qpwc_version(void);
+const char* qpwc_last_error(void);
+const char* qpwc_strerror(int code);
+
+/* CostVolume / CostVolumeV2 forward.
+ * Replaces: CostVolume.call           qpwcnet/core/layers.py:72-100
+ *           CostVolumeV2.call         qpwcnet/core/layers.py:128-132, i.e. the op
+ *           tfa CorrelationCost(kernel_size=1, max_displacement=r, stride_1=1,
+ *           stride_2=1, pad=r, data_format) + leaky_relu   (layers.py:124-125,131)
+ *           and their functor twins   qpwcnet/core/non_layers.py:72-104, 119-123.
+ *   d = 2*search_range+1
+ *   out[b,y,x,i*d+j] = lrelu( (1/C) * sum_c prv[b,y,x,c] * nxt[b,y+i-r,x+j-r,c] ),
+ *   nxt taken as zero outside the image; lrelu(v) = v > 0 ? v : slope*v.
+ * prv, nxt: (B,H,W,C) or (B,C,H,W) dense; out: (B,H,W,d*d) or (B,d*d,H,W) dense. */
+int qpwc_cost_volume_fwd(const void* prv, const void* nxt, void* out,
+                         int B, int H, int W, int C, int search_range,
+                         int layout, int dtype, float lrelu_slope, void* stream);
+
+/* Same computation, writing into a wider channels-last buffer: pixel p's d*d
+ * results go to out + p*out_pixel_stride + out_channel_offset (in elements).
+ * This is how Flow/UpFlow's concat([cost, prv, ...]) (non_layers.py:332-338,
+ * 381-385) is fed without a copy.  NHWC only. */
+int qpwc_cost_volume_fwd_strided(const void* prv, const void* nxt, void* out,
+                                 int B, int H, int W, int C, int search_range,
+                                 int dtype, float lrelu_slope,
+                                 int64_t out_pixel_stride, int64_t out_channel_offset,
+                                 void* stream);
+
+/* Warp / WarpV2 forward.
+ * Replaces: WarpV2.call  qpwcnet/core/layers.py:177-186 (non_layers.py:147-158):
+ *             tfa.image.dense_image_warp(img, -flo[..., ::-1])  -> mode CLAMP
+ *           Warp.call    qpwcnet/core/layers.py:166-168 -> tf_warp,
+ *             qpwcnet/core/warp.py:63-153                       -> mode TFWARP
+ * Samples img at (y + flo[...,1], x + flo[...,0]) bilinearly.
+ * img/out: (B,H,W,C) or (B,C,H,W) of `dtype`; flo: same layout with 2 channels
+ * (x, y), ALWAYS fp32 (coordinates need the precision); flow dims flagged in flo_bcast_mask have extent 1 (e.g. a (1,1,1,2) flow,
+ * qpwcnet/app/optical_flow/test_warp.py:32) and flo is dense over the rest. */
+int qpwc_warp_fwd(const void* img, const void* flo, void* out,
+                  int B, int H, int W, int C, int flo_bcast_mask,
+                  int layout, int dtype, int mode, void* stream);
+
+/* UpFlow front end in one launch (non_layers.py:377-385):
+ *   nxt_w = WarpV2(nxt, flo); cost = CostVolumeV2(prv, nxt_w)
+ * without materialising nxt_w.  NHWC, mode CLAMP, flo dense (B,H,W,2) fp32,
+ * search_range 4, C % 4 == 0.  Output addressing as in
+ * qpwc_cost_volume_fwd_strided (pass stride d*d, offset 0 for a dense result). */
+int qpwc_warp_cost_volume_fwd(const void* prv, const void* nxt, const void* flo, void* out,
+                              int B, int H, int W, int C, int search_range,
+                              int dtype, float lrelu_slope,
+                              int64_t out_pixel_stride, int64_t out_channel_offset,
+                              void* stream);
+
+/* End-point error (qpwcnet/app/optical_flow/train.py:247-253):
+ *   *out_mean = mean over (b,y,x) of || y_true - y_pred ||_2 over the 2 flow channels.
+ * fp32 flows of shape (B,H,W,2) / (B,2,H,W).  workspace: >= qpwc_epe_workspace_floats()
+ * floats of device scratch owned by the caller (deterministic two-stage sum). */
+int qpwc_epe_workspace_floats(void);
+int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* workspace,
+                 int B, int H, int W, int layout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPWC_H_ */

@@ -1,0 +1,127 @@
+"""torch-CPU restatement of the reference's ``build_flower`` graph
+(qpwcnet/core/pwcnet.py:28-67,134-244; blocks qpwcnet/core/non_layers.py) with
+the op-for-op hot path of ``oracle/torch_ref.py``.  Test infrastructure and the
+cpu_baseline leg only.  PARITY UNPINNED -- see ``oracle/__init__.py``.
+
+Written independently of ``qpwcnet_amd`` (it shares only the weight dictionary):
+channels_last tensors throughout, explicit TF 'SAME' padding.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import torch_ref
+
+ENC = 5
+DEC = 4
+BN_EPS = 1e-3  # Keras BatchNormalization default
+
+
+def _c(x):   # NHWC -> NCHW
+    return x.permute(0, 3, 1, 2)
+
+
+def _l(x):   # NCHW -> NHWC
+    return x.permute(0, 2, 3, 1)
+
+
+def _tf_same_conv(x, w, b, stride):
+    """Keras Conv2D(padding='same') on NCHW."""
+    k = w.shape[2]
+    pads = []
+    for size in (x.shape[3], x.shape[2]):  # F.pad order: W first
+        out = -(-size // stride)
+        total = max((out - 1) * stride + k - size, 0)
+        pads += [total // 2, total - total // 2]
+    return F.conv2d(F.pad(x, pads), w, b, stride=stride)
+
+
+def mish(x):
+    """qpwcnet/core/mish.py:27-28."""
+    return x * torch.tanh(F.softplus(x))
+
+
+class RefNet:
+    def __init__(self, weights, dtype=torch.float32):
+        self.dtype = dtype
+        self.w = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in weights.items()}
+
+    def down_conv(self, i, x):                      # non_layers.py:390-449, no normalizer
+        y = _c(x)
+        for name, s in (("conv_a", 2), ("conv_aa", 1), ("conv_b", 1)):
+            p = "enc.{}.{}".format(i, name)
+            y = mish(_tf_same_conv(y, self.w[p + ".weight"], self.w[p + ".bias"], s))
+        return _l(y)
+
+    def up_conv(self, i, x):                        # non_layers.py:196-210
+        p = "dec.{}.conv_up".format(i)
+        y = F.conv_transpose2d(_c(x), self.w[p + ".weight"], self.w[p + ".bias"], stride=2, padding=1)
+        return _l(mish(y))
+
+    def opt_flow(self, prefix, feat):               # non_layers.py:213-273
+        h, w = feat.shape[1], feat.shape[2]
+        scale = float(h ** 2 + w ** 2) ** 0.5
+        x = _c(feat)
+        for i in range(4):
+            dw = self.w["{}feat.{}.depthwise.weight".format(prefix, i)]
+            x = F.conv2d(x, dw, None, padding=1, groups=dw.shape[0])
+            x = F.conv2d(x, self.w["{}feat.{}.pointwise.weight".format(prefix, i)],
+                         self.w["{}feat.{}.bias".format(prefix, i)])
+            x = mish(x)
+        x = mish(F.conv2d(x, self.w[prefix + "conv.weight"], self.w[prefix + "conv.bias"]))
+        g, b = self.w[prefix + "norm.gamma"], self.w[prefix + "norm.beta"]
+        m, v = self.w[prefix + "norm.mean"], self.w[prefix + "norm.var"]
+        x = (x - m.view(1, -1, 1, 1)) / torch.sqrt(v.view(1, -1, 1, 1) + BN_EPS) \
+            * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        f = F.conv2d(x, self.w[prefix + "flow.weight"], None, padding=1)
+        return _l(scale * f)
+
+    @staticmethod
+    def upsample(x, scale):                         # non_layers.py:183-193
+        y = F.interpolate(_c(x), scale_factor=2, mode="bilinear", align_corners=False)
+        return _l(scale * y)
+
+    @torch.no_grad()
+    def __call__(self, inputs):
+        """inputs (B,H,W,6) -> list of the 6 multi-scale flows (pwcnet.py:28-67)."""
+        x = torch.as_tensor(inputs).to(self.dtype)
+        img_prv, img_nxt = x[..., :3], x[..., 3:]   # Split(2), pwcnet.py:229
+        encs = []
+        for img in (img_prv, img_nxt):              # pwcnet.py:134-168 (shared weights)
+            f, feats = img, [img]
+            for i in range(ENC):
+                f = self.down_conv(i, f)
+                feats.append(f)
+            encs.append(feats)
+        decs = []
+        for feats in encs:                          # pwcnet.py:171-207
+            f, out, k = feats[-1], [], -2
+            for i in range(DEC):
+                f = torch.cat([self.up_conv(i, f), feats[k]], dim=3)
+                k -= 1
+                out.append(f)
+            decs.append(out)
+        prv, nxt = encs[0][-1], encs[1][-1]
+        cost = torch_ref.cost_volume(prv, nxt)      # Flow, non_layers.py:332-338
+        flo = self.opt_flow("flow.flow.", torch.cat([cost, prv, nxt], dim=3))
+        flos = [flo]
+        for i in range(DEC):                        # pwcnet.py:43-57
+            flo_u = self.upsample(flo, 2.0)
+            prv, nxt = decs[0][i], decs[1][i]
+            nxt_w = torch_ref.warp_v2(nxt, flo_u)   # UpFlow, non_layers.py:377-385
+            cost = torch_ref.cost_volume(prv, nxt_w)
+            flo = self.opt_flow("upflow.{}.flow.".format(i), torch.cat([cost, prv, flo_u], dim=3))
+            flos.append(flo)
+        flos.append(self.upsample(flo, 2.0))        # pwcnet.py:60
+        return flos
+
+
+def multiscale_gt(flow_gt, shapes):
+    """Per-level ground truth of FlowMseLoss: bilinear resize to (h,w), times h/H
+    (qpwcnet/train/loss.py:56-62)."""
+    H = flow_gt.shape[1]
+    out = []
+    for (h, w) in shapes:
+        y = F.interpolate(_c(flow_gt), size=(h, w), mode="bilinear", align_corners=False)
+        out.append(_l(y) * (h / H))
+    return out

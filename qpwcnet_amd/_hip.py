@@ -1,0 +1,83 @@
+"""ctypes binding of ``libqpwc_hip.so`` (C ABI declared in ``include/qpwc.h``).
+
+There is deliberately no fallback: if the library is missing or a call fails
+the error propagates.  PyTorch is used only for device memory and streams; the
+ABI itself sees raw device pointers.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqpwc_hip.so")
+
+NHWC, NCHW = 0, 1
+F32, F16 = 0, 1
+WARP_CLAMP, WARP_TFWARP = 0, 1
+BCAST_B, BCAST_H, BCAST_W = 1, 2, 4
+
+E_NULL, E_LAYOUT, E_DTYPE, E_SHAPE, E_RANGE, E_MODE, E_ALIAS, E_LAUNCH, E_ALIGN, E_STRIDE, \
+    E_NODEVICE = range(-1, -12, -1)
+_ARGUMENT_ERRORS = {E_NULL, E_LAYOUT, E_DTYPE, E_SHAPE, E_RANGE, E_MODE, E_ALIAS, E_ALIGN, E_STRIDE}
+
+# every symbol include/qpwc.h declares
+SYMBOLS = (
+    "qpwc_version", "qpwc_last_error", "qpwc_strerror",
+    "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
+    "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
+)
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles on CPU)."""
+    import subprocess
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "qpwcnet_amd: {} is missing -- build it with `make -C qpwcnet_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU "
+            "fallback.".format(LIB_PATH))
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+    L.qpwc_version.argtypes = []
+    L.qpwc_version.restype = ci
+    L.qpwc_last_error.argtypes = []
+    L.qpwc_last_error.restype = ctypes.c_char_p
+    L.qpwc_strerror.argtypes = [ci]
+    L.qpwc_strerror.restype = ctypes.c_char_p
+    L.qpwc_cost_volume_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp]
+    L.qpwc_cost_volume_fwd.restype = ci
+    L.qpwc_cost_volume_fwd_strided.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, i64, i64, vp]
+    L.qpwc_cost_volume_fwd_strided.restype = ci
+    L.qpwc_warp_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.qpwc_warp_fwd.restype = ci
+    L.qpwc_warp_cost_volume_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, i64, i64, vp]
+    L.qpwc_warp_cost_volume_fwd.restype = ci
+    L.qpwc_epe_workspace_floats.argtypes = []
+    L.qpwc_epe_workspace_floats.restype = ci
+    L.qpwc_epe_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.qpwc_epe_fwd.restype = ci
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Map a QPWC_E_* code to the exception the reference would raise."""
+    if rc == 0:
+        return
+    L = lib()
+    msg = "{} ({})".format(L.qpwc_last_error().decode(), L.qpwc_strerror(rc).decode())
+    if rc in _ARGUMENT_ERRORS:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

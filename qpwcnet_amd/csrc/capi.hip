@@ -1,0 +1,180 @@
+// extern "C" boundary of libqpwc_hip.so (declared in include/qpwc.h).
+// Validates arguments, then enqueues on the caller's stream.  No allocation,
+// no synchronisation, no global state besides a thread-local error string.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace qpwc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return QPWC_E_LAUNCH;
+    }
+    return QPWC_OK;
+}
+
+int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* out, int B, int H,
+                       int W, int C, int r, int layout, int dtype, int64_t ops, float slope,
+                       bool fuse, hipStream_t s);
+int warp_launch(const void* img, const void* flo, void* out, int B, int H, int W, int C,
+                int flo_bcast_mask, int layout, int dtype, int mode, hipStream_t s);
+int epe_workspace_floats();
+int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int H, int W,
+               int layout, hipStream_t s);
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static size_t esize(int dtype) { return dtype == QPWC_F16 ? 2 : 4; }
+
+static bool overlaps(const void* a, size_t na, const void* b, size_t nb) {
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a0 < b0 + nb && b0 < a0 + na;
+}
+
+static int check_common(int B, int H, int W, int C, int layout, int dtype) {
+    if (layout != QPWC_NHWC && layout != QPWC_NCHW)
+        return fail(QPWC_E_LAYOUT, "Unsupported data format : %d", layout);
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0)
+        return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d C=%d", B, H, W, C);
+    return QPWC_OK;
+}
+
+static int cost_volume_checked(const void* prv, const void* nxt, const void* flo, void* out, int B,
+                               int H, int W, int C, int r, int layout, int dtype, float slope,
+                               int64_t ops, int64_t off, bool strided, bool fuse, void* stream) {
+    if (!prv || !nxt || !out || (fuse && !flo)) return fail(QPWC_E_NULL, "null pointer argument");
+    int rc = check_common(B, H, W, C, layout, dtype);
+    if (rc != QPWC_OK) return rc;
+    if (r < 0 || r > 16) return fail(QPWC_E_RANGE, "search_range %d outside [0,16]", r);
+    if (fuse && (H < 2 || W < 2))
+        return fail(QPWC_E_SHAPE, "warp needs H,W >= 2 (got %dx%d)", H, W);
+    const int64_t DD = (int64_t)(2 * r + 1) * (2 * r + 1);
+    if (!strided) {
+        ops = DD;
+        off = 0;
+    } else if (off < 0 || ops < off + DD) {
+        return fail(QPWC_E_STRIDE, "out_pixel_stride %lld cannot hold %lld channels at offset %lld",
+                    (long long)ops, (long long)DD, (long long)off);
+    }
+    const size_t es = esize(dtype);
+    if ((uintptr_t)prv % es || (uintptr_t)nxt % es || (uintptr_t)out % es ||
+        (fuse && (uintptr_t)flo % 4))
+        return fail(QPWC_E_ALIGN, "pointer not aligned to its element size");
+    const size_t n_in = (size_t)B * H * W * C * es;
+    const size_t n_out = ((size_t)B * H * W * ops) * es;
+    if (overlaps(out, n_out, prv, n_in) || overlaps(out, n_out, nxt, n_in) ||
+        (fuse && overlaps(out, n_out, flo, (size_t)B * H * W * 2 * 4)))
+        return fail(QPWC_E_ALIAS, "out overlaps an input");
+    char* o = (char*)out + (size_t)off * es;
+    return cost_volume_launch(prv, nxt, flo, o, B, H, W, C, r, layout, dtype, ops, slope, fuse,
+                              (hipStream_t)stream);
+}
+
+}  // namespace qpwc
+
+using namespace qpwc;
+
+extern "C" {
+
+int qpwc_version(void) { return QPWC_VERSION; }
+
+const char* qpwc_last_error(void) { return g_err; }
+
+const char* qpwc_strerror(int code) {
+    switch (code) {
+        case QPWC_OK: return "ok";
+        case QPWC_E_NULL: return "null pointer";
+        case QPWC_E_LAYOUT: return "unsupported data format";
+        case QPWC_E_DTYPE: return "unsupported dtype";
+        case QPWC_E_SHAPE: return "bad shape";
+        case QPWC_E_RANGE: return "bad search range";
+        case QPWC_E_MODE: return "unknown warp mode";
+        case QPWC_E_ALIAS: return "output aliases an input";
+        case QPWC_E_LAUNCH: return "kernel launch failed";
+        case QPWC_E_ALIGN: return "misaligned pointer";
+        case QPWC_E_STRIDE: return "bad output stride/offset";
+        case QPWC_E_NODEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+int qpwc_cost_volume_fwd(const void* prv, const void* nxt, void* out, int B, int H, int W, int C,
+                         int search_range, int layout, int dtype, float lrelu_slope, void* stream) {
+    return cost_volume_checked(prv, nxt, nullptr, out, B, H, W, C, search_range, layout, dtype,
+                               lrelu_slope, 0, 0, false, false, stream);
+}
+
+int qpwc_cost_volume_fwd_strided(const void* prv, const void* nxt, void* out, int B, int H, int W,
+                                 int C, int search_range, int dtype, float lrelu_slope,
+                                 int64_t out_pixel_stride, int64_t out_channel_offset, void* stream) {
+    return cost_volume_checked(prv, nxt, nullptr, out, B, H, W, C, search_range, QPWC_NHWC, dtype,
+                               lrelu_slope, out_pixel_stride, out_channel_offset, true, false,
+                               stream);
+}
+
+int qpwc_warp_cost_volume_fwd(const void* prv, const void* nxt, const void* flo, void* out, int B,
+                              int H, int W, int C, int search_range, int dtype, float lrelu_slope,
+                              int64_t out_pixel_stride, int64_t out_channel_offset, void* stream) {
+    return cost_volume_checked(prv, nxt, flo, out, B, H, W, C, search_range, QPWC_NHWC, dtype,
+                               lrelu_slope, out_pixel_stride, out_channel_offset, true, true, stream);
+}
+
+int qpwc_warp_fwd(const void* img, const void* flo, void* out, int B, int H, int W, int C,
+                  int flo_bcast_mask, int layout, int dtype, int mode, void* stream) {
+    if (!img || !flo || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    int rc = check_common(B, H, W, C, layout, dtype);
+    if (rc != QPWC_OK) return rc;
+    if (mode != QPWC_WARP_CLAMP && mode != QPWC_WARP_TFWARP)
+        return fail(QPWC_E_MODE, "unknown warp mode %d", mode);
+    if (mode == QPWC_WARP_CLAMP && (H < 2 || W < 2))
+        return fail(QPWC_E_SHAPE, "Grid must be at least 2x2 (got %dx%d)", H, W);
+    if (flo_bcast_mask & ~(QPWC_BCAST_B | QPWC_BCAST_H | QPWC_BCAST_W))
+        return fail(QPWC_E_SHAPE, "bad flo_bcast_mask %d", flo_bcast_mask);
+    const size_t es = esize(dtype);
+    if ((uintptr_t)img % es || (uintptr_t)out % es || (uintptr_t)flo % 4)
+        return fail(QPWC_E_ALIGN, "pointer not aligned to its element size");
+    const size_t n = (size_t)B * H * W * C * es;
+    const size_t nf = (size_t)((flo_bcast_mask & QPWC_BCAST_B) ? 1 : B) *
+                      ((flo_bcast_mask & QPWC_BCAST_H) ? 1 : H) *
+                      ((flo_bcast_mask & QPWC_BCAST_W) ? 1 : W) * 2 * 4;
+    if (overlaps(out, n, img, n) || overlaps(out, n, flo, nf))
+        return fail(QPWC_E_ALIAS, "out overlaps an input");
+    return warp_launch(img, flo, out, B, H, W, C, flo_bcast_mask, layout, dtype, mode,
+                       (hipStream_t)stream);
+}
+
+int qpwc_epe_workspace_floats(void) { return epe_workspace_floats(); }
+
+int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* workspace, int B,
+                 int H, int W, int layout, void* stream) {
+    if (!y_true || !y_pred || !out_mean || !workspace) return fail(QPWC_E_NULL, "null pointer argument");
+    int rc = check_common(B, H, W, 2, layout, QPWC_F32);
+    if (rc != QPWC_OK) return rc;
+    if ((uintptr_t)y_true % 8 || (uintptr_t)y_pred % 8 || (uintptr_t)out_mean % 4 ||
+        (uintptr_t)workspace % 4)
+        return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte aligned");
+    return epe_launch((const float*)y_true, (const float*)y_pred, (float*)out_mean,
+                      (float*)workspace, B, H, W, layout, (hipStream_t)stream);
+}
+
+}  // extern "C"

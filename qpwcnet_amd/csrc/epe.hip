@@ -1,0 +1,85 @@
+// End-point error reduction (qpwcnet/app/optical_flow/train.py:247-253):
+//   mean over (b,y,x) of || y_true - y_pred ||_2 along the 2-channel flow axis.
+// Deterministic two-stage sum: kEpeBlocks partials, then one block folds them.
+#include "common.h"
+
+namespace qpwc {
+
+constexpr int kEpeBlocks = 256;
+constexpr int kEpeThreads = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float r = 0.0f;
+    if (wid == 0) {
+        r = lane < (int)(blockDim.x >> 6) ? red[lane] : 0.0f;
+        r = wave_sum(r);
+    }
+    return r;  // valid in thread 0
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kEpeThreads) void epe_partial_kernel(const float* __restrict__ a,
+                                                                  const float* __restrict__ b,
+                                                                  float* __restrict__ partial,
+                                                                  int64_t npix, int64_t plane) {
+    __shared__ float red[kEpeThreads / 64];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float dx, dy;
+        if (LAYOUT == QPWC_NHWC) {
+            const float2 va = reinterpret_cast<const float2*>(a)[i];
+            const float2 vb = reinterpret_cast<const float2*>(b)[i];
+            dx = va.x - vb.x;
+            dy = va.y - vb.y;
+        } else {
+            const int64_t bi = i / plane, r = i % plane;
+            const int64_t o = bi * 2 * plane + r;
+            dx = a[o] - b[o];
+            dy = a[o + plane] - b[o + plane];
+        }
+        s += sqrtf(dx * dx + dy * dy);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kEpeThreads) void epe_final_kernel(const float* __restrict__ partial,
+                                                                float* __restrict__ out, int n,
+                                                                float inv_npix) {
+    __shared__ float red[kEpeThreads / 64];
+    float s = (int)threadIdx.x < n ? partial[threadIdx.x] : 0.0f;
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = s * inv_npix;
+}
+
+int epe_workspace_floats() { return kEpeBlocks; }
+
+int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int H, int W,
+               int layout, hipStream_t s) {
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t plane = (int64_t)H * W;
+    if (layout == QPWC_NHWC)
+        hipLaunchKernelGGL((epe_partial_kernel<QPWC_NHWC>), dim3(kEpeBlocks), dim3(kEpeThreads), 0,
+                           s, a, b, ws, npix, plane);
+    else
+        hipLaunchKernelGGL((epe_partial_kernel<QPWC_NCHW>), dim3(kEpeBlocks), dim3(kEpeThreads), 0,
+                           s, a, b, ws, npix, plane);
+    int rc = check_launch("epe_partial_kernel");
+    if (rc != QPWC_OK) return rc;
+    hipLaunchKernelGGL(epe_final_kernel, dim3(1), dim3(kEpeThreads), 0, s, ws, out, kEpeBlocks,
+                       1.0f / (float)npix);
+    return check_launch("epe_final_kernel");
+}
+
+}  // namespace qpwc

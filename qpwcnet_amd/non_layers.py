@@ -1,0 +1,260 @@
+"""Plain-callable twins of the reference's functor layers
+(qpwcnet/core/non_layers.py) -- the classes ``pwcnet.py`` actually instantiates.
+
+Hot path (HIP kernels): ``CostVolume``, ``CostVolumeV2``, ``Warp``, ``WarpV2``
+(non_layers.py:51-158).  Surrounding blocks (PyTorch-ROCm): ``Split``,
+``Upsample``, ``UpConv``, ``DownConv``, ``OptFlow``, ``Flow``, ``UpFlow``.
+
+Tensors cross every block boundary in the declared data format, like the
+reference.  Convolutions run on logical-NCHW views; for ``channels_last`` those
+views are torch channels_last memory, i.e. nothing is transposed or copied.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .backend import CHANNELS_FIRST, CHANNELS_LAST, get_axis, image_data_format
+
+
+def _get_axis(data_format):
+    return get_axis(data_format)
+
+
+def parse_image_shape(tensor, data_format=None):
+    """qpwcnet/core/non_layers.py:19-30."""
+    if data_format is None:
+        data_format = image_data_format()
+    if data_format == CHANNELS_FIRST:
+        n, c, h, w = tensor.shape
+    else:
+        n, h, w, c = tensor.shape
+    return {"n": n, "c": c, "h": h, "w": w}
+
+
+def lrelu(x):
+    return F.leaky_relu(x, 0.1)
+
+
+class _Functor:
+    def __init__(self, *args, data_format=None, **kwargs):
+        if args or kwargs:
+            raise TypeError("unexpected arguments: {} {}".format(args, sorted(kwargs)))
+        self.data_format = image_data_format() if data_format is None else data_format
+        self.axis = _get_axis(self.data_format)
+
+    # logical-NCHW view for torch convs, and back
+    def _nchw(self, x):
+        return x.permute(0, 3, 1, 2) if self.data_format == CHANNELS_LAST else x
+
+    def _fmt(self, x):
+        return x.permute(0, 2, 3, 1) if self.data_format == CHANNELS_LAST else x
+
+
+# --------------------------------------------------------------------------
+# hot path
+# --------------------------------------------------------------------------
+class CostVolume(_Functor):
+    """qpwcnet/core/non_layers.py:51-104."""
+
+    def __init__(self, search_range=4, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.search_range = search_range
+
+    def __call__(self, inputs):
+        prv, nxt = inputs
+        return ops.cost_volume(prv, nxt, self.search_range, self.data_format, 0.1)
+
+
+class CostVolumeV2(CostVolume):
+    """qpwcnet/core/non_layers.py:107-123 (tfa CorrelationCost + lrelu): same kernel."""
+
+
+class Warp(_Functor):
+    """qpwcnet/core/non_layers.py:126-134 -> tf_warp."""
+
+    def __call__(self, inputs):
+        img, flo = inputs
+        return ops.warp(img, flo, "tfwarp", self.data_format)
+
+
+class WarpV2(_Functor):
+    """qpwcnet/core/non_layers.py:137-158 -> tfa dense_image_warp(img, -flo[..., ::-1])."""
+
+    def __call__(self, inputs):
+        img, flo = inputs
+        return ops.warp(img, flo, "clamp", self.data_format)
+
+
+# --------------------------------------------------------------------------
+# surrounding network (PyTorch-ROCm)
+# --------------------------------------------------------------------------
+def _same_pad(size, k, s):
+    """TensorFlow 'SAME' padding (before, after) for one spatial dim."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
+def conv2d_same(x, weight, bias, stride):
+    """Keras Conv2D(padding='same') on a logical-NCHW tensor.  For stride 2 on even
+    sizes the padding is asymmetric (0 before, 1 after), unlike torch padding=1."""
+    kh, kw = weight.shape[2], weight.shape[3]
+    pt, pb = _same_pad(x.shape[2], kh, stride)
+    pl, pr = _same_pad(x.shape[3], kw, stride)
+    if pt == pb and pl == pr:
+        return F.conv2d(x, weight, bias, stride=stride, padding=(pt, pl))
+    return F.conv2d(F.pad(x, (pl, pr, pt, pb)), weight, bias, stride=stride)
+
+
+class Split(_Functor):
+    """qpwcnet/core/non_layers.py:161-168 (tf.split into `num` equal parts)."""
+
+    def __init__(self, num=2, axis=-1, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.num = num
+        self.split_axis = axis
+
+    def __call__(self, x):
+        return torch.chunk(x, self.num, dim=self.split_axis)
+
+
+class Upsample(_Functor):
+    """qpwcnet/core/non_layers.py:183-193: scale * UpSampling2D(2, 'bilinear')
+    (half-pixel centres == align_corners=False)."""
+
+    def __init__(self, scale=1.0, *args, **kwargs):
+        kwargs.pop("sacle", None)  # reference typo at non_layers.py:468 leaves scale = 1.0
+        kwargs.pop("name", None)
+        super().__init__(*args, **kwargs)
+        self.scale = scale
+
+    def __call__(self, x):
+        y = F.interpolate(self._nchw(x), scale_factor=2, mode="bilinear", align_corners=False)
+        return self._fmt(y * self.scale)
+
+
+class _Weighted(_Functor):
+    """Block with parameters: looked up by name in a flat ``{name: tensor}`` dict
+    (torch layouts) held by the model, so the same weights drive the CPU oracle."""
+
+    def __init__(self, params, prefix, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.params = params
+        self.prefix = prefix
+
+    def p(self, name):
+        return self.params[self.prefix + name]
+
+
+class UpConv(_Weighted):
+    """qpwcnet/core/non_layers.py:196-210: Conv2DTranspose(k=4, s=2, 'same') + Mish
+    == ConvTranspose2d(k=4, s=2, padding=1)."""
+
+    def __call__(self, x):
+        y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), self.p("conv_up.bias"),
+                               stride=2, padding=1)
+        return self._fmt(F.mish(y))
+
+
+class DownConv(_Weighted):
+    """qpwcnet/core/non_layers.py:390-449 with use_normalizer=False (pwcnet.py:146):
+    3x3 s2 conv + Mish, 3x3 s1 conv + Mish, 3x3 s1 conv + Mish, TF 'same' padding."""
+
+    def __call__(self, x):
+        y = self._nchw(x)
+        y = F.mish(conv2d_same(y, self.p("conv_a.weight"), self.p("conv_a.bias"), 2))
+        y = F.mish(conv2d_same(y, self.p("conv_aa.weight"), self.p("conv_aa.bias"), 1))
+        y = F.mish(conv2d_same(y, self.p("conv_b.weight"), self.p("conv_b.bias"), 1))
+        return self._fmt(y)
+
+
+class OptFlow(_Weighted):
+    """qpwcnet/core/non_layers.py:213-273: 4x [SeparableConv2D 3x3 + Mish] ->
+    1x1 conv + Mish -> BatchNorm (inference, eps 1e-3) -> 3x3 conv (no bias),
+    times sqrt(h^2 + w^2) of the input's spatial size."""
+
+    BN_EPS = 1e-3
+
+    def __init__(self, params, prefix, filters=(128, 64, 32, 16), scale=None, *args, **kwargs):
+        super().__init__(params, prefix, *args, **kwargs)
+        self.filters = tuple(filters)
+        self.scale = scale
+
+    def __call__(self, inputs):
+        shape = parse_image_shape(inputs, self.data_format)
+        scale = self.scale
+        if scale is None:
+            scale = float(shape["h"] ** 2 + shape["w"] ** 2) ** 0.5
+        x = self._nchw(inputs)
+        for i in range(len(self.filters)):
+            dw = self.p("feat.{}.depthwise.weight".format(i))
+            x = F.conv2d(x, dw, None, stride=1, padding=1, groups=dw.shape[0])
+            x = F.conv2d(x, self.p("feat.{}.pointwise.weight".format(i)),
+                         self.p("feat.{}.bias".format(i)))
+            x = F.mish(x)
+        x = F.mish(F.conv2d(x, self.p("conv.weight"), self.p("conv.bias")))
+        x = F.batch_norm(x, self.p("norm.mean"), self.p("norm.var"), self.p("norm.gamma"),
+                         self.p("norm.beta"), training=False, eps=self.BN_EPS)
+        f = F.conv2d(x, self.p("flow.weight"), None, stride=1, padding=1)
+        return self._fmt(scale * f)
+
+
+class Flow(_Weighted):
+    """First flow block, qpwcnet/core/non_layers.py:315-338:
+    cost = cv(prv, nxt); OptFlow(concat[cost, prv, nxt])."""
+
+    def __init__(self, params, prefix, use_tfa=True, *args, **kwargs):
+        super().__init__(params, prefix, *args, **kwargs)
+        self.flow = OptFlow(params, prefix + "flow.", data_format=self.data_format)
+        cls = CostVolumeV2 if use_tfa else CostVolume
+        self.cost_volume = cls(data_format=self.data_format)
+
+    def __call__(self, inputs):
+        prv, nxt = inputs
+        cost = self.cost_volume((prv, nxt))
+        feat = torch.cat([cost, prv, nxt], dim=self.axis)
+        return self.flow(feat)
+
+
+class UpFlow(_Weighted):
+    """Refinement block, qpwcnet/core/non_layers.py:341-387:
+    nxt_w = WarpV2(nxt, flo); cost = cv(prv, nxt_w); OptFlow(concat[cost, prv, flo]).
+
+    fused=True (channels_last only) produces the same ``feat`` with one
+    warp+cost-volume launch writing straight into the concat buffer."""
+
+    def __init__(self, params, prefix, use_tfa=True, fused=False, *args, **kwargs):
+        super().__init__(params, prefix, *args, **kwargs)
+        self._config = {"use_tfa": use_tfa}
+        self.flow = OptFlow(params, prefix + "flow.", data_format=self.data_format)
+        self.warp = WarpV2(data_format=self.data_format)
+        cls = CostVolumeV2 if use_tfa else CostVolume
+        self.cost_volume = cls(data_format=self.data_format)
+        self.fused = bool(fused) and self.data_format == CHANNELS_LAST
+
+    def __call__(self, inputs):
+        prv, nxt, flo = inputs
+        if self.fused:
+            feat = self._fused_feat(prv, nxt, flo)
+        else:
+            nxt_w = self.warp((nxt, flo))
+            cost = self.cost_volume((prv, nxt_w))
+            feat = torch.cat([cost, prv, flo], dim=self.axis)
+        return self.flow(feat)
+
+    def _fused_feat(self, prv, nxt, flo):
+        B, H, W, C = prv.shape
+        d2 = (2 * self.cost_volume.search_range + 1) ** 2
+        feat = torch.empty((B, H, W, d2 + C + 2), dtype=prv.dtype, device=prv.device)
+        flo32 = flo.to(torch.float32).contiguous()
+        ops.cost_volume_into(prv.contiguous(), nxt.contiguous(), feat, 0,
+                             self.cost_volume.search_range, 0.1, flo=flo32)
+        feat[..., d2:d2 + C] = prv
+        feat[..., d2 + C:] = flo
+        return feat
+
+
+def scale_of(h, w):
+    return math.sqrt(h * h + w * w)

@@ -1,0 +1,255 @@
+"""Functional entry points of the hot path: torch tensors in, HIP kernels underneath.
+
+Each function validates shapes/dtypes/devices the way the reference's graph
+construction would, then calls the C ABI (``include/qpwc.h``) on the caller's
+current HIP stream.  There is no CPU path: a non-GPU tensor is an error.
+"""
+import torch
+
+from . import _hip
+from .backend import CHANNELS_FIRST, CHANNELS_LAST, get_axis
+
+_DTYPES = {torch.float32: _hip.F32, torch.float16: _hip.F16}
+
+
+class KernelTimer:
+    """HIP-event timing of the hot-path launches, on the stream they are launched
+    on (the caller's current stream).  Used by bench.py for the live roofline:
+
+        with ops.kernel_timing() as kt:
+            model(x)
+        kt.summary()  # {(op, B, H, W, C): (launches, mean_ms)}
+    """
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _TIMER
+        self._prev, _TIMER = _TIMER, self
+        return self
+
+    def __exit__(self, *exc):
+        global _TIMER
+        _TIMER = self._prev
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        acc = {}
+        for key, e0, e1 in self.records:
+            n, t = acc.get(key, (0, 0.0))
+            acc[key] = (n + 1, t + e0.elapsed_time(e1))
+        return {k: (n, t / n) for k, (n, t) in acc.items()}
+
+
+_TIMER = None
+
+
+def kernel_timing():
+    return KernelTimer()
+
+
+class _timed:
+    __slots__ = ("key", "e0")
+
+    def __init__(self, op, dims):
+        self.key = (op,) + tuple(dims)
+
+    def __enter__(self):
+        if _TIMER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMER is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _TIMER.records.append((self.key, self.e0, e1))
+        return False
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _check_tensor(name, t):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("{} must be a torch.Tensor".format(name))
+    if not t.is_cuda:
+        raise RuntimeError(
+            "qpwcnet_amd: {} is on '{}'; the hot path runs on a HIP device only "
+            "(no CPU fallback)".format(name, t.device))
+    if t.dtype not in _DTYPES:
+        raise ValueError("{}: unsupported dtype {}".format(name, t.dtype))
+    if t.dim() != 4:
+        # the reference's tf_warp breaks on unbatched input too (warp.py:75-79)
+        raise ValueError("{} must be rank 4 (batched), got shape {}".format(name, tuple(t.shape)))
+
+
+def _physical(t, data_format):
+    """-> (dense tensor, layout code, (B,H,W,C), nhwc_view_of_nchw).
+
+    A ``channels_first`` tensor stored in torch's channels_last memory format is
+    physically NHWC: hand it to the NHWC kernels through a permuted view."""
+    get_axis(data_format)  # raises ValueError('Unsupported data format')
+    if data_format == CHANNELS_LAST:
+        t = t.contiguous()
+        B, H, W, C = t.shape
+        return t, _hip.NHWC, (B, H, W, C), False
+    B, C, H, W = t.shape
+    if C > 1 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
+        return t.permute(0, 2, 3, 1), _hip.NHWC, (B, H, W, C), True
+    return t.contiguous(), _hip.NCHW, (B, H, W, C), False
+
+
+def _empty_like_layout(ref, dims, channels, layout, as_nchw_view):
+    B, H, W, _ = dims
+    if layout == _hip.NHWC:
+        buf = torch.empty((B, H, W, channels), dtype=ref.dtype, device=ref.device)
+        return buf, (buf.permute(0, 3, 1, 2) if as_nchw_view else buf)
+    buf = torch.empty((B, channels, H, W), dtype=ref.dtype, device=ref.device)
+    return buf, buf
+
+
+def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST, lrelu_slope=0.1):
+    """CostVolume / CostVolumeV2 forward (reference: qpwcnet/core/layers.py:72-100,128-132)."""
+    _check_tensor("prv", prv)
+    _check_tensor("nxt", nxt)
+    if prv.shape != nxt.shape:
+        raise ValueError("prv and nxt must have the same shape, got {} and {}".format(
+            tuple(prv.shape), tuple(nxt.shape)))
+    if prv.dtype != nxt.dtype or prv.device != nxt.device:
+        raise ValueError("prv and nxt must share dtype and device")
+    p, layout, dims, as_view = _physical(prv, data_format)
+    n, layout_n, _, _ = _physical(nxt, data_format)
+    if layout_n != layout:  # mixed memory formats: fall back to the declared layout
+        p, n = prv.contiguous(), nxt.contiguous()
+        layout, as_view = (_hip.NCHW if data_format == CHANNELS_FIRST else _hip.NHWC), False
+    B, H, W, C = dims
+    d = 2 * int(search_range) + 1
+    buf, out = _empty_like_layout(p, dims, d * d, layout, as_view)
+    with torch.cuda.device(p.device), _timed("cost_volume", dims):
+        rc = _hip.lib().qpwc_cost_volume_fwd(
+            p.data_ptr(), n.data_ptr(), buf.data_ptr(), B, H, W, C, int(search_range), layout,
+            _DTYPES[p.dtype], float(lrelu_slope), _stream(p))
+    _hip.check(rc)
+    return out
+
+
+def _flow_physical(flo, dims, data_format, layout):
+    """fp32 flow, dense over its non-broadcast dims, in the layout the image uses."""
+    B, H, W, _ = dims
+    if flo.dim() != 4:
+        raise ValueError("flo must be rank 4, got shape {}".format(tuple(flo.shape)))
+    if data_format == CHANNELS_LAST:
+        fb, fh, fw, fc = flo.shape
+    else:
+        fb, fc, fh, fw = flo.shape
+    if fc != 2:
+        raise ValueError("flo must have 2 channels (x, y), got {}".format(fc))
+    mask = 0
+    for ext, full, bit in ((fb, B, _hip.BCAST_B), (fh, H, _hip.BCAST_H), (fw, W, _hip.BCAST_W)):
+        if ext == full:
+            continue
+        if ext != 1:
+            raise ValueError("flo shape {} is not broadcastable to the image".format(
+                tuple(flo.shape)))
+        mask |= bit
+    f = flo.to(torch.float32)
+    if data_format == CHANNELS_FIRST and layout == _hip.NHWC:
+        f = f.permute(0, 2, 3, 1)  # image is physically NHWC: give the flow the same layout
+    return f.contiguous(), mask
+
+
+def warp(img, flo, mode="clamp", data_format=CHANNELS_LAST):
+    """Warp (mode 'tfwarp', qpwcnet/core/warp.py:63-153) / WarpV2 (mode 'clamp',
+    qpwcnet/core/layers.py:177-186): sample img at (y + flo[...,1], x + flo[...,0])."""
+    _check_tensor("img", img)
+    if not isinstance(flo, torch.Tensor) or not flo.is_cuda or flo.device != img.device:
+        raise RuntimeError("flo must be a tensor on the same HIP device as img")
+    if mode not in ("clamp", "tfwarp"):
+        raise ValueError("unknown warp mode '{}'".format(mode))
+    i, layout, dims, as_view = _physical(img, data_format)
+    B, H, W, C = dims
+    f, mask = _flow_physical(flo, dims, data_format, layout)
+    buf, out = _empty_like_layout(i, dims, C, layout, as_view)
+    with torch.cuda.device(i.device), _timed("warp_" + mode, dims):
+        rc = _hip.lib().qpwc_warp_fwd(
+            i.data_ptr(), f.data_ptr(), buf.data_ptr(), B, H, W, C, mask, layout,
+            _DTYPES[i.dtype], _hip.WARP_CLAMP if mode == "clamp" else _hip.WARP_TFWARP,
+            _stream(i))
+    _hip.check(rc)
+    return out
+
+
+def cost_volume_into(prv, nxt, out, channel_offset=0, search_range=4, lrelu_slope=0.1, flo=None):
+    """NHWC cost volume written into channels [offset, offset+d*d) of the wider
+    channels-last buffer ``out`` (B,H,W,Ctot) -- Flow/UpFlow's concat target
+    (qpwcnet/core/non_layers.py:332-338, 381-385).  With ``flo`` the WarpV2 of
+    ``nxt`` is fused in (non_layers.py:377-380) and ``nxt_w`` never exists."""
+    _check_tensor("prv", prv)
+    _check_tensor("nxt", nxt)
+    _check_tensor("out", out)
+    if prv.shape != nxt.shape or prv.dtype != nxt.dtype or out.dtype != prv.dtype:
+        raise ValueError("prv, nxt (and out's dtype) must match")
+    if not (prv.is_contiguous() and nxt.is_contiguous() and out.is_contiguous()):
+        raise ValueError("cost_volume_into needs dense NHWC tensors")
+    B, H, W, C = prv.shape
+    if out.shape[:3] != prv.shape[:3]:
+        raise ValueError("out must be (B,H,W,Ctot) with the image's B,H,W")
+    L = _hip.lib()
+    with torch.cuda.device(prv.device), \
+            _timed("cost_volume" if flo is None else "warp_cost_volume", (B, H, W, C)):
+        if flo is None:
+            rc = L.qpwc_cost_volume_fwd_strided(
+                prv.data_ptr(), nxt.data_ptr(), out.data_ptr(), B, H, W, C, int(search_range),
+                _DTYPES[prv.dtype], float(lrelu_slope), out.shape[3], int(channel_offset),
+                _stream(prv))
+        else:
+            if tuple(flo.shape) != (B, H, W, 2) or flo.dtype != torch.float32 or \
+                    not flo.is_contiguous() or flo.device != prv.device:
+                raise ValueError("flo must be a dense fp32 (B,H,W,2) tensor on the same device")
+            rc = L.qpwc_warp_cost_volume_fwd(
+                prv.data_ptr(), nxt.data_ptr(), flo.data_ptr(), out.data_ptr(), B, H, W, C,
+                int(search_range), _DTYPES[prv.dtype], float(lrelu_slope), out.shape[3],
+                int(channel_offset), _stream(prv))
+    _hip.check(rc)
+    return out
+
+
+def warp_cost_volume(prv, nxt, flo, search_range=4, lrelu_slope=0.1):
+    """cost_volume(prv, WarpV2(nxt, flo)) in one launch; NHWC, dense result."""
+    d = 2 * int(search_range) + 1
+    out = torch.empty(prv.shape[:3] + (d * d,), dtype=prv.dtype, device=prv.device)
+    return cost_volume_into(prv, nxt, out, 0, search_range, lrelu_slope, flo=flo)
+
+
+def epe(y_true, y_pred, data_format=CHANNELS_LAST):
+    """End-point error, qpwcnet/app/optical_flow/train.py:247-253 -> 0-dim tensor."""
+    for name, t in (("y_true", y_true), ("y_pred", y_pred)):
+        _check_tensor(name, t)
+        if t.dtype != torch.float32:
+            raise ValueError("{} must be float32".format(name))
+    if y_true.shape != y_pred.shape:
+        raise ValueError("y_true and y_pred must have the same shape")
+    get_axis(data_format)
+    a, b = y_true.contiguous(), y_pred.contiguous()
+    if data_format == CHANNELS_LAST:
+        B, H, W, C = a.shape
+        layout = _hip.NHWC
+    else:
+        B, C, H, W = a.shape
+        layout = _hip.NCHW
+    if C != 2:
+        raise ValueError("flows must have 2 channels")
+    L = _hip.lib()
+    # per-call scratch: stream-ordered reuse across concurrent streams would race
+    ws = torch.empty(L.qpwc_epe_workspace_floats(), dtype=torch.float32, device=a.device)
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = L.qpwc_epe_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), ws.data_ptr(), B, H, W,
+                            layout, _stream(a))
+    _hip.check(rc)
+    return out

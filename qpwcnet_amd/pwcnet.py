@@ -1,0 +1,119 @@
+"""Model assembly mirroring qpwcnet/core/pwcnet.py: ``encoder`` (134-168),
+``decoder`` (171-207), ``flower`` (28-67), ``build_flower`` (210-244).
+
+The hot path (cost volume + warp, 5 + 4 launches per pair) runs in the HIP
+kernels; everything else is PyTorch-ROCm (MIOpen / hipBLASLt).  Inference only.
+"""
+import numpy as np
+import torch
+
+from .backend import CHANNELS_FIRST, CHANNELS_LAST, get_axis, image_data_format
+from .non_layers import DownConv, Flow, Split, UpConv, UpFlow, Upsample
+from .synth import DEC_FILTERS, ENC_FILTERS, make_weights
+
+
+def encoder(layers, img_prv, img_nxt, output_features=False):
+    """pwcnet.py:134-168: the same five DownConv blocks applied to both frames."""
+    f = img_prv
+    feats_prv = [f]
+    for l in layers:
+        f = l(f)
+        feats_prv.append(f)
+    f = img_nxt
+    feats_nxt = [f]
+    for l in layers:
+        f = l(f)
+        feats_nxt.append(f)
+    if output_features:
+        return feats_prv, feats_nxt
+    return feats_prv[-1], feats_nxt[-1]
+
+
+def decoder(layers, encs_prv, encs_nxt, axis, use_skip=True):
+    """pwcnet.py:171-207: four UpConv blocks, each concatenated with the encoder
+    feature of the same resolution."""
+    def run(encs):
+        f = encs[-1]
+        i = -2
+        decs = []
+        for l in layers:
+            f = l(f)
+            if use_skip:
+                f = torch.cat([f, encs[i]], dim=axis)
+                i -= 1
+            decs.append(f)
+        return decs
+    return run(encs_prv), run(encs_nxt)
+
+
+def flower(flow, upflows, enc_prv, enc_nxt, decs_prv, decs_nxt, data_format,
+           output_multiscale=True):
+    """pwcnet.py:28-67: coarsest Flow, then per level Upsample(x2, *2) + UpFlow,
+    and a final upsample-only full-resolution flow."""
+    flo_01 = flow((enc_prv, enc_nxt))
+    flos = [flo_01]
+    for i in range(len(decs_prv)):
+        flo_01_u = Upsample(scale=2.0, data_format=data_format)(flo_01)
+        flo_01 = upflows[i]((decs_prv[i], decs_nxt[i], flo_01_u))
+        flos.append(flo_01)
+    flo_01 = Upsample(scale=2.0, data_format=data_format)(flo_01)
+    flos.append(flo_01)
+    return flos if output_multiscale else [flo_01]
+
+
+class QpwcNet:
+    """What ``build_flower`` returns: ``model(inputs)`` / ``model.predict(inputs)``
+    with inputs (B,H,W,6) ('channels_last') or (B,6,H,W); returns the list of 6
+    multi-scale flows when ``train`` (pwcnet.py:237-239) else the final flow only."""
+
+    def __init__(self, weights, train=True, input_shape=(256, 512), data_format=None,
+                 use_tfa=True, device="cuda", dtype=torch.float32, fused=False):
+        self.data_format = image_data_format() if data_format is None else data_format
+        self.axis = get_axis(self.data_format)
+        self.train = train
+        self.input_shape = tuple(input_shape)
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.params = {}
+        for k, v in weights.items():
+            t = torch.as_tensor(np.asarray(v)).to(self.device, dtype)
+            if t.dim() == 4 and self.data_format == CHANNELS_LAST:
+                t = t.contiguous(memory_format=torch.channels_last)
+            self.params[k] = t
+        df = self.data_format
+        self.split = Split(2, axis=self.axis, data_format=df)
+        self.enc = [DownConv(self.params, "enc.{}.".format(i), data_format=df)
+                    for i in range(len(ENC_FILTERS))]
+        self.dec = [UpConv(self.params, "dec.{}.".format(i), data_format=df)
+                    for i in range(len(DEC_FILTERS))]
+        self.flow = Flow(self.params, "flow.", use_tfa=use_tfa, data_format=df)
+        self.upflows = [UpFlow(self.params, "upflow.{}.".format(i), use_tfa=use_tfa, fused=fused,
+                               data_format=df) for i in range(len(DEC_FILTERS))]
+
+    def __call__(self, inputs):
+        exp = (self.input_shape + (6,)) if self.data_format == CHANNELS_LAST \
+            else ((6,) + self.input_shape)
+        if tuple(inputs.shape[1:]) != exp:
+            raise ValueError("expected input shape (B,)+{}, got {}".format(exp, tuple(inputs.shape)))
+        img_prv, img_nxt = self.split(inputs)
+        encs_prv, encs_nxt = encoder(self.enc, img_prv, img_nxt, True)
+        decs_prv, decs_nxt = decoder(self.dec, encs_prv, encs_nxt, self.axis, True)
+        outs = flower(self.flow, self.upflows, encs_prv[-1], encs_nxt[-1], decs_prv, decs_nxt,
+                      self.data_format, output_multiscale=self.train)
+        return outs if self.train else outs[0]
+
+    @torch.no_grad()
+    def predict(self, inputs):
+        if isinstance(inputs, np.ndarray):
+            inputs = torch.from_numpy(inputs)
+        return self(inputs.to(self.device, self.dtype))
+
+
+def build_flower(train=True, input_shape=(256, 512), data_format=None, use_tfa=True,
+                 weights=None, device="cuda", dtype=torch.float32, fused=False):
+    """pwcnet.py:210-244.  ``weights``: flat dict from ``synth.make_weights`` (default:
+    seed 42), since no checkpoint ships with the reference."""
+    if weights is None:
+        weights = make_weights(42, input_shape)
+    return QpwcNet(weights, train=train, input_shape=input_shape, data_format=data_format,
+                   use_tfa=use_tfa, device=device, dtype=dtype, fused=fused)

@@ -1,0 +1,298 @@
+"""GPU suite (-m gpu): the HIP path, called through the layer facades and the C
+ABI, against the committed golden vectors and the CPU oracle on the same seeded
+inputs.  Tolerance: BASELINE.json north_star -- 1e-4 absolute in fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import c_ref, np_ref, net_ref, torch_ref
+from qpwcnet_amd import layers, non_layers, ops, synth, warp as warp_mod
+from qpwcnet_amd.backend import image_data_format, set_image_data_format
+from qpwcnet_amd.pwcnet import build_flower
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4      # north_star: "within 1e-4 fp32 on identical inputs"
+DEV = "cuda:0"
+
+
+def gpu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def _facade(mod, name):
+    op, fmt, shape, seed, extra = cases.CASES[name]
+    if op == "cost_volume":
+        return mod.CostVolumeV2(search_range=extra.get("search_range", 4), data_format=fmt)
+    if op == "warp_v2":
+        return mod.WarpV2(data_format=fmt)
+    return mod.Warp(data_format=fmt)
+
+
+def _oracle_f32(name):
+    op, fmt, shape, seed, extra = cases.CASES[name]
+    a, b = cases.make_inputs(name)
+    if op == "cost_volume":
+        return c_ref.cost_volume(a, b, extra.get("search_range", 4), fmt)
+    return c_ref.warp(a, b, fmt, "clamp" if op == "warp_v2" else "tfwarp")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _loaded():
+    from qpwcnet_amd import _hip
+    assert os.path.exists(_hip.LIB_PATH), "libqpwc_hip.so must be built in-tree"
+    _hip.lib()
+    c_ref.build()
+
+
+@pytest.mark.parametrize("mod", [layers, non_layers], ids=["layers", "non_layers"])
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_golden_and_oracle(name, mod):
+    a, b = cases.make_inputs(name)
+    out = _facade(mod, name)((gpu(a), gpu(b))).cpu().numpy()
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert tuple(out.shape) == tuple(g["shape"])
+    flat = out.reshape(-1).astype(np.float64)
+    np.testing.assert_allclose(flat[g["idx"]], g["val"], rtol=0, atol=TOL)
+    assert abs(flat.sum() - g["total"]) <= 1e-5 * max(1.0, g["abs_total"])
+    np.testing.assert_allclose(out, _oracle_f32(name), rtol=0, atol=TOL)
+
+
+def test_warp_is_bit_exact_against_the_unfused_c_oracle():
+    """Same fp32 op sequence, no FMA contraction on either side."""
+    for name in ("warp2_test_nhwc", "warp1_test_nhwc", "warp2_border", "warp1_border", "warp2_L4"):
+        a, b = cases.make_inputs(name)
+        out = _facade(non_layers, name)((gpu(a), gpu(b))).cpu().numpy()
+        np.testing.assert_array_equal(out, _oracle_f32(name), err_msg=name)
+
+
+def test_reference_invariant_v1_equals_v2():
+    """qpwcnet/app/test/test_cvol_equal.py:9-25: (v0 - v1).sum() == 0.0, both layouts."""
+    fmt0 = image_data_format()
+    try:
+        for cn in ("channels_first", "channels_last"):
+            set_image_data_format(cn)
+            shape = (1, 3, 128, 256) if cn == "channels_first" else (1, 128, 256, 3)
+            rng = np.random.default_rng(99)
+            prv, nxt = rng.standard_normal(shape).astype(np.float32), rng.standard_normal(shape).astype(np.float32)
+            v0 = layers.CostVolume(4)((gpu(prv), gpu(nxt)))
+            v1 = layers.CostVolumeV2(4)((gpu(prv), gpu(nxt)))
+            assert float((v0 - v1).sum()) == 0.0
+            np.testing.assert_allclose(v0.cpu().numpy(), np_ref.cost_volume(prv, nxt, 4, cn), atol=TOL)
+    finally:
+        set_image_data_format(fmt0)
+
+
+def test_known_answer_3x3_and_broadcast_flow():
+    """qpwcnet/app/optical_flow/test_warp.py:28-33, flow broadcast from (1,1,1,2)."""
+    g = np.load(os.path.join(GOLDEN, "known_3x3.npz"))
+    out = layers.WarpV2(data_format="channels_last")((gpu(g["nxt"]), gpu(g["flo"]))).cpu().numpy()
+    expect = np.zeros((3, 3), np.float32)
+    expect[1, 0] = 1.0
+    np.testing.assert_array_equal(out[0, ..., 0], expect)
+    out1 = layers.Warp(data_format="channels_last")((gpu(g["nxt"]), gpu(g["flo"]))).cpu().numpy()
+    np.testing.assert_array_equal(out1, g["tf_warp"])
+    # partial broadcasts
+    rng = np.random.default_rng(3)
+    img = rng.random((3, 9, 11, 8)).astype(np.float32)
+    for fshape in ((1, 9, 11, 2), (3, 1, 11, 2), (3, 9, 1, 2), (1, 1, 1, 2)):
+        flo = rng.standard_normal(fshape).astype(np.float32) * 2
+        for mode, ref in (("clamp", np_ref.warp_v2), ("tfwarp", np_ref.tf_warp)):
+            o = ops.warp(gpu(img), gpu(flo), mode).cpu().numpy()
+            np.testing.assert_allclose(o, ref(img, flo), atol=1e-6, err_msg=str(fshape))
+
+
+def test_zero_flow_known_answers():
+    rng = np.random.default_rng(4)
+    img = rng.random((2, 16, 20, 12)).astype(np.float32)
+    flo = np.zeros((2, 16, 20, 2), np.float32)
+    v2 = ops.warp(gpu(img), gpu(flo), "clamp").cpu().numpy()
+    np.testing.assert_allclose(v2, img, rtol=0, atol=1.2e-7)
+    v1 = ops.warp(gpu(img), gpu(flo), "tfwarp").cpu().numpy()
+    np.testing.assert_array_equal(v1[:, :-1, :-1], img[:, :-1, :-1])
+    assert np.all(v1[:, -1] == 0) and np.all(v1[:, :, -1] == 0)
+
+
+def test_function_level_mirrors():
+    rng = np.random.default_rng(5)
+    img = rng.random((2, 10, 12, 4)).astype(np.float32)
+    flo = rng.standard_normal((2, 10, 12, 2)).astype(np.float32)
+    np.testing.assert_array_equal(warp_mod.tf_warp(gpu(img), gpu(flo), "channels_last").cpu().numpy(),
+                                  np_ref.tf_warp(img, flo))
+    np.testing.assert_array_equal(warp_mod.dense_image_warp(gpu(img), gpu(flo)).cpu().numpy(),
+                                  np_ref.dense_image_warp(img, flo))
+
+
+def test_channels_first_stored_channels_last():
+    """A logical NCHW tensor in torch channels_last memory takes the NHWC kernels."""
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((2, 16, 24, 32)).astype(np.float32)
+    b = rng.standard_normal((2, 16, 24, 32)).astype(np.float32)
+    f = rng.standard_normal((2, 16, 24, 2)).astype(np.float32) * 3
+    an, bn, fn = (gpu(x).permute(0, 3, 1, 2) for x in (a, b, f))    # NCHW views of NHWC memory
+    cv = ops.cost_volume(an, bn, 4, "channels_first")
+    assert cv.shape == (2, 81, 16, 24) and cv.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(cv.permute(0, 2, 3, 1).cpu().numpy(), c_ref.cost_volume(a, b), atol=TOL)
+    w = ops.warp(an, fn, "clamp", "channels_first")
+    np.testing.assert_array_equal(w.permute(0, 2, 3, 1).cpu().numpy(), c_ref.warp(a, f))
+
+
+def test_strided_output_into_concat_buffer():
+    rng = np.random.default_rng(7)
+    B, H, W, C = 2, 20, 28, 16
+    prv = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    nxt = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    feat = torch.full((B, H, W, 81 + C + 2), 7.0, device=DEV)
+    ops.cost_volume_into(gpu(prv), gpu(nxt), feat, 0)
+    ref = c_ref.cost_volume(prv, nxt)
+    np.testing.assert_allclose(feat[..., :81].cpu().numpy(), ref, atol=TOL)
+    assert bool((feat[..., 81:] == 7.0).all())          # nothing else touched
+    feat2 = torch.full((B, H, W, 100), 7.0, device=DEV)
+    ops.cost_volume_into(gpu(prv), gpu(nxt), feat2, 10)
+    np.testing.assert_allclose(feat2[..., 10:91].cpu().numpy(), ref, atol=TOL)
+    assert bool((feat2[..., :10] == 7.0).all()) and bool((feat2[..., 91:] == 7.0).all())
+    with pytest.raises(ValueError):
+        ops.cost_volume_into(gpu(prv), gpu(nxt), feat2, 30)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 256), (1, 64, 128, 64), (2, 19, 37, 8), (8, 8, 16, 32)])
+def test_fused_warp_cost_volume(shape):
+    """UpFlow front end (non_layers.py:377-380) in one launch == warp then cost volume."""
+    rng = np.random.default_rng(8)
+    prv = rng.standard_normal(shape).astype(np.float32)
+    nxt = rng.standard_normal(shape).astype(np.float32)
+    flo = (rng.standard_normal(shape[:3] + (2,)) * 3).astype(np.float32)
+    fused = ops.warp_cost_volume(gpu(prv), gpu(nxt), gpu(flo)).cpu().numpy()
+    ref = c_ref.cost_volume(prv, c_ref.warp(nxt, flo))
+    np.testing.assert_allclose(fused, ref, rtol=0, atol=TOL)
+    unfused = ops.cost_volume(gpu(prv), ops.warp(gpu(nxt), gpu(flo), "clamp")).cpu().numpy()
+    np.testing.assert_allclose(fused, unfused, rtol=0, atol=1e-5)
+
+
+def test_epe():
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((3, 33, 47, 2)).astype(np.float32)
+    b = rng.standard_normal((3, 33, 47, 2)).astype(np.float32)
+    ref = c_ref.epe(a, b)
+    assert abs(float(ops.epe(gpu(a), gpu(b))) - ref) < 1e-5
+    an, bn = np.transpose(a, (0, 3, 1, 2)), np.transpose(b, (0, 3, 1, 2))
+    assert abs(float(ops.epe(gpu(an), gpu(bn), "channels_first")) - ref) < 1e-5
+
+
+def test_fp16_storage_path():
+    """Config 5: fp16 storage, fp32 accumulate.  The reference has no fp16 path; the
+    bound is build-defined: oracle on the fp16-rounded inputs, output rounding only."""
+    rng = np.random.default_rng(10)
+    for shape in ((2, 16, 32, 64), (2, 9, 13, 6)):
+        a = rng.standard_normal(shape).astype(np.float16)
+        b = rng.standard_normal(shape).astype(np.float16)
+        f = (rng.standard_normal(shape[:3] + (2,)) * 2).astype(np.float32)
+        cv = ops.cost_volume(gpu(a), gpu(b)).float().cpu().numpy()
+        ref = c_ref.cost_volume(a.astype(np.float32), b.astype(np.float32))
+        np.testing.assert_allclose(cv, ref, rtol=1e-3, atol=1e-3)
+        w = ops.warp(gpu(a), gpu(f), "clamp").float().cpu().numpy()
+        np.testing.assert_allclose(w, c_ref.warp(a.astype(np.float32), f), rtol=1e-3, atol=1e-3)
+
+
+def test_error_behaviour_on_device():
+    x = torch.zeros(1, 8, 8, 4, device=DEV)
+    with pytest.raises(ValueError, match="Unsupported data format"):
+        ops.cost_volume(x, x, 4, "nhwc")
+    with pytest.raises(ValueError):
+        ops.cost_volume(x, torch.zeros(1, 8, 9, 4, device=DEV))
+    with pytest.raises(ValueError):
+        ops.warp(x[0], torch.zeros(8, 8, 2, device=DEV))                 # unbatched
+    with pytest.raises(ValueError, match="at least 2x2"):
+        ops.warp(torch.zeros(1, 1, 8, 4, device=DEV), torch.zeros(1, 1, 8, 2, device=DEV))
+    with pytest.raises(ValueError):
+        ops.warp(x, torch.zeros(1, 8, 8, 3, device=DEV))
+    with pytest.raises(ValueError):
+        ops.cost_volume(x, x, search_range=-1)
+    # tf_warp has no 2x2 restriction
+    ops.warp(torch.zeros(1, 1, 8, 4, device=DEV), torch.zeros(1, 1, 8, 2, device=DEV), "tfwarp")
+
+
+# ---- BASELINE.json full sizes: oracle where it finishes in seconds, plus
+# ---- size-independent properties ------------------------------------------
+LEVELS_256 = [(8, 16, 256), (16, 32, 256), (32, 64, 128), (64, 128, 64), (128, 256, 32)]
+
+
+@pytest.mark.parametrize("hwc", LEVELS_256)
+def test_config2_level_shapes_batch8(hwc):
+    H, W, C = hwc
+    rng = np.random.default_rng(20 + H)
+    shape = (8, H, W, C)
+    prv = rng.standard_normal(shape).astype(np.float32)
+    nxt = rng.standard_normal(shape).astype(np.float32)
+    flo = (rng.standard_normal((8, H, W, 2)) * 4).astype(np.float32)
+    cv = ops.cost_volume(gpu(prv), gpu(nxt)).cpu().numpy()
+    np.testing.assert_allclose(cv, c_ref.cost_volume(prv, nxt), rtol=0, atol=TOL)
+    w = ops.warp(gpu(nxt), gpu(flo), "clamp").cpu().numpy()
+    np.testing.assert_array_equal(w, c_ref.warp(nxt, flo))
+    fused = ops.warp_cost_volume(gpu(prv), gpu(nxt), gpu(flo)).cpu().numpy()
+    np.testing.assert_allclose(fused, c_ref.cost_volume(prv, w), rtol=0, atol=TOL)
+
+
+def test_config4_sintel_full_level_properties():
+    """1024x2048 finest level (512,1024,32), B=2: properties that need no oracle."""
+    g = torch.Generator(device=DEV).manual_seed(0)
+    B, H, W, C = 2, 512, 1024, 32
+    prv = torch.randn(B, H, W, C, device=DEV, generator=g)
+    # (1) shifted copy: the matching displacement channel equals mean(prv^2) in the interior
+    dy, dx = 3, -2
+    nxt = torch.roll(prv, (dy, dx), dims=(1, 2))
+    cv = ops.cost_volume(prv, nxt)
+    k = (dy + 4) * 9 + (dx + 4)
+    auto = (prv * prv).mean(dim=3)
+    assert torch.allclose(cv[:, 8:-8, 8:-8, k], auto[:, 8:-8, 8:-8], atol=1e-5)
+    assert bool((cv[:, 8:-8, 8:-8].argmax(dim=3) == k).float().mean() > 0.999)
+    # (2) positive homogeneity: cv(a*prv, nxt) == a*cv(prv, nxt), a > 0 (lrelu is homogeneous)
+    cv2 = ops.cost_volume(2.0 * prv, nxt)
+    assert torch.allclose(cv2, 2.0 * cv, atol=1e-5)
+    # (3) zero padding: displacement (-4,-4) at the top-left corner is all padding
+    assert float(cv[:, 0, 0, 0].abs().max()) == 0.0
+    # (4) integer flow == roll in the interior, and fused == unfused
+    flo = torch.zeros(B, H, W, 2, device=DEV)
+    flo[..., 0], flo[..., 1] = 2.0, -1.0
+    w = ops.warp(prv, flo, "clamp")
+    assert torch.equal(w[:, 4:-4, 4:-4], torch.roll(prv, (1, -2), dims=(1, 2))[:, 4:-4, 4:-4])
+    fused = ops.warp_cost_volume(prv, nxt, flo)
+    assert torch.allclose(fused, ops.cost_volume(prv, ops.warp(nxt, flo, "clamp")), atol=1e-5)
+    # (5) spot check against the numpy oracle on a crop far from the borders
+    ys, xs = slice(200, 232), slice(500, 532)
+    crop = np_ref.cost_volume(prv[:1, 192:240, 492:540].cpu().numpy(), nxt[:1, 192:240, 492:540].cpu().numpy())
+    np.testing.assert_allclose(cv[:1, ys, xs].cpu().numpy(), crop[:, 8:40, 8:40], atol=TOL)
+
+
+# ---- whole network: GPU (HIP hot path + PyTorch-ROCm convs) vs CPU oracle ---
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+@pytest.mark.parametrize("hw,batch", [((64, 128), 2), ((256, 512), 1)])
+def test_full_network_per_level_epe(hw, batch, fused):
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(batch, hw[0], hw[1], seed=1234)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV, fused=fused)
+    flows = model.predict(pairs)
+    ref = net_ref.RefNet(weights)(pairs)
+    assert len(flows) == 6
+    for lvl, (a, b) in enumerate(zip(flows, ref)):
+        assert tuple(a.shape) == tuple(b.shape)
+        e = float(torch_ref.epe_error(a.cpu(), b))
+        assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
+    # inference graph (train=False) returns only the full-resolution flow
+    last = build_flower(False, hw, "channels_last", weights=weights, device=DEV, fused=fused).predict(pairs)
+    assert torch.equal(last, flows[-1])
+
+
+def test_full_network_channels_first():
+    hw = (64, 128)
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(1, hw[0], hw[1], seed=1234)
+    model = build_flower(True, hw, "channels_first", weights=weights, device=DEV)
+    flows = model.predict(np.ascontiguousarray(np.transpose(pairs, (0, 3, 1, 2))))
+    ref = net_ref.RefNet(weights)(pairs)
+    for a, b in zip(flows, ref):
+        assert float(torch_ref.epe_error(a.permute(0, 2, 3, 1).cpu(), b)) < TOL

@@ -1,0 +1,112 @@
+"""CPU suite: host-side logic of the layer facades (construction, config round
+trip, data-format handling, error behaviour) -- everything up to the device call."""
+import numpy as np
+import pytest
+import torch
+
+import qpwcnet_amd
+from qpwcnet_amd import layers, non_layers, ops, synth
+from qpwcnet_amd.backend import get_axis, image_data_format, set_image_data_format
+
+
+@pytest.fixture(autouse=True)
+def _restore_format():
+    fmt = image_data_format()
+    yield
+    set_image_data_format(fmt)
+
+
+def test_global_data_format_is_read_at_construction():
+    """layers.py:41,119,146,173 -- tf.keras.backend.image_data_format() at __init__."""
+    assert image_data_format() == "channels_last"
+    a = layers.CostVolume(4)
+    set_image_data_format("channels_first")
+    b = layers.CostVolume(4)
+    c = non_layers.WarpV2()
+    set_image_data_format("channels_last")
+    assert (a.data_format, a.axis) == ("channels_last", 3)
+    assert (b.data_format, b.axis) == ("channels_first", 1)
+    assert c.data_format == "channels_first"
+    with pytest.raises(ValueError):
+        set_image_data_format("nhwc")
+
+
+def test_explicit_data_format_kwarg():
+    """What test/test_cost_volume.py:10-11 and test/test_warp.py:14-15 try to pass."""
+    assert layers.CostVolumeV2(search_range=4, data_format="channels_first").axis == 1
+    assert layers.Warp(data_format="channels_first").data_format == "channels_first"
+    with pytest.raises(ValueError, match="Unsupported data format"):
+        layers.WarpV2(data_format="NHWC")
+    with pytest.raises(ValueError, match="Unsupported data format"):
+        get_axis("bogus")
+
+
+def test_unknown_kwargs_rejected_like_keras():
+    with pytest.raises(TypeError):
+        layers.CostVolume(4, bogus=1)
+
+
+def test_config_round_trip():
+    """layers.py:102-109."""
+    l = layers.CostVolume(search_range=3, name="cv")
+    cfg = l.get_config()
+    assert cfg["search_range"] == 3 and cfg["name"] == "cv"
+    l2 = layers.CostVolume.from_config(cfg)
+    assert l2.search_range == 3
+    assert layers.CostVolumeV2.from_config(layers.CostVolumeV2(2).get_config()).search_range == 2
+
+
+def test_build_captures_hw():
+    """layers.py:57-70."""
+    l = layers.CostVolume(data_format="channels_first")
+    l.build(((2, 5, 7, 9), (2, 5, 7, 9)))
+    assert (l.h, l.w) == (7, 9)
+    l = layers.Warp(data_format="channels_last")
+    l.build(((2, 7, 9, 5), (2, 7, 9, 2)))
+    assert (l.h, l.w) == (7, 9)
+
+
+def test_cpu_tensor_is_an_error_not_a_fallback():
+    x = torch.zeros(1, 8, 8, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layers.CostVolume()((x, x))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        non_layers.WarpV2()((x, torch.zeros(1, 8, 8, 2)))
+    with pytest.raises(RuntimeError):
+        ops.epe(torch.zeros(1, 4, 4, 2), torch.zeros(1, 4, 4, 2))
+
+
+def test_same_padding_rule():
+    """TF 'SAME': stride-2 3x3 on an even size pads (0, 1); on odd sizes (1, 1)."""
+    assert non_layers._same_pad(256, 3, 2) == (0, 1)
+    assert non_layers._same_pad(255, 3, 2) == (1, 1)
+    assert non_layers._same_pad(16, 3, 1) == (1, 1)
+    assert non_layers._same_pad(16, 1, 1) == (0, 0)
+    x = torch.arange(36, dtype=torch.float32).reshape(1, 1, 6, 6)
+    w = torch.ones(1, 1, 3, 3)
+    y = non_layers.conv2d_same(x, w, None, 2)
+    assert y.shape == (1, 1, 3, 3)
+    assert float(y[0, 0, 0, 0]) == float(x[0, 0, :3, :3].sum())          # no padding before
+    assert float(y[0, 0, 2, 2]) == float(x[0, 0, 4:, 4:].sum())          # padded after
+
+
+def test_synthetic_weights_shape_and_determinism():
+    w1, w2 = synth.make_weights(42), synth.make_weights(42)
+    assert sum(v.size for v in w1.values()) == 3094165     # 3.09 M parameters
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+    assert synth.level_channels() == [256, 256, 128, 64, 32]
+    assert w1["flow.flow.feat.0.depthwise.weight"].shape == (593, 1, 3, 3)
+    assert w1["upflow.3.flow.feat.0.depthwise.weight"].shape == (115, 1, 3, 3)
+
+
+def test_synthetic_frames():
+    p, f = synth.make_frames(2, 32, 64, seed=1234)
+    p2, _ = synth.make_frames(2, 32, 64, seed=1234)
+    assert p.shape == (2, 32, 64, 6) and f.shape == (2, 32, 64, 2)
+    assert p.dtype == np.float32 and np.array_equal(p, p2)
+    assert p.min() >= -0.5 and p.max() <= 0.5
+    assert np.abs(f).max() <= 8.0
+
+
+def test_version():
+    assert qpwcnet_amd.__version__
