@@ -48,6 +48,14 @@ def lib():
             "qpwcnet_amd: {} is missing -- build it with `make -C qpwcnet_amd/csrc` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU "
             "fallback.".format(LIB_PATH))
+    # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Load it
+    # FIRST so that our NEEDED entry binds to that same runtime instance: a second
+    # HIP runtime in the process cannot see torch's streams or allocations
+    # ("no ROCm-capable device is detected" at the first launch).
+    import torch
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cf, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
     L.qpwc_version.argtypes = []

@@ -59,7 +59,8 @@ __global__ __launch_bounds__((CvCfg<R, TH, TW, CC>::NT)) void cost_volume_tiled_
     constexpr int D = Cfg::D, DD = Cfg::DD, NT = Cfg::NT, NCH = Cfg::NCH, P = Cfg::P;
     constexpr int NH = Cfg::NH, NW = Cfg::NW, RSN = Cfg::RSN, RSP = Cfg::RSP;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // static LDS (up to 160 KiB per workgroup on gfx950): no launch-time attribute needed
+    __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
     float4* nxt_s = reinterpret_cast<float4*>(smem);
     float4* prv_s = nxt_s + Cfg::NXT_SLOTS;
 
@@ -224,24 +225,13 @@ static int launch_tiled(const T* prv, const T* nxt, const float* flo, T* out, in
                         int C, int64_t ops, float slope, hipStream_t s) {
     using Cfg = CvCfg<4, TH, TW, CC>;
     auto kern = cost_volume_tiled_kernel<T, 4, TH, TW, CC, FUSE>;
-    static bool attr_set = false;  // idempotent; a benign race sets it twice
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Cfg::LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("hipFuncSetAttribute(LDS=%d) failed", Cfg::LDS_BYTES);
-            return QPWC_E_LAUNCH;
-        }
-        attr_set = true;
-    }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
     if (nblk > INT32_MAX) {
         set_error("grid too large");
         return QPWC_E_SHAPE;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), Cfg::LDS_BYTES, s, prv, nxt, flo,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), 0, s, prv, nxt, flo,
                        out, H, W, C, tiles_x, tiles_y, ops, slope);
     return check_launch("cost_volume_tiled_kernel");
 }

@@ -284,7 +284,7 @@ def test_full_network_per_level_epe(hw, batch, fused):
         assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
     # inference graph (train=False) returns only the full-resolution flow
     last = build_flower(False, hw, "channels_last", weights=weights, device=DEV, fused=fused).predict(pairs)
-    assert torch.equal(last, flows[-1])
+    assert torch.allclose(last, flows[-1], rtol=0, atol=1e-5)  # conv solvers may differ run to run
 
 
 def test_full_network_channels_first():

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Kernel-only micro-benchmark of the hot path at the BASELINE level shapes.
+
+    python tools/kbench.py [--batch 8] [--iters 50] [--res 256x512] [--ops cv,warp,fused]
+
+Inputs N(0,1) / U[0,1) / N(0,1)*4 as in SURVEY.md 8(d).  Interleaves the shapes in
+one process (rule 24 of the CDNA guide) and reports median/min launch time from HIP
+events, algorithmic GB/s and the fraction of the 8 TB/s HBM peak.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qpwcnet_amd import ops  # noqa: E402
+
+PEAK = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--res", default="256x512")
+    ap.add_argument("--ops", default="cv,warp,fused")
+    ap.add_argument("--levels", default="0,1,2,3,4")
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    H0, W0 = map(int, a.res.split("x"))
+    chans = [256, 256, 128, 64, 32]
+    dt = torch.float32 if a.dtype == "f32" else torch.float16
+    es = 4 if a.dtype == "f32" else 2
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    cases = []
+    for l in map(int, a.levels.split(",")):
+        H, W, C = H0 >> (5 - l), W0 >> (5 - l), chans[l]
+        prv = torch.randn(a.batch, H, W, C, device=dev, generator=g).to(dt)
+        nxt = torch.randn(a.batch, H, W, C, device=dev, generator=g).to(dt)
+        img = torch.rand(a.batch, H, W, C, device=dev, generator=g).to(dt)
+        flo = torch.randn(a.batch, H, W, 2, device=dev, generator=g) * 4
+        n = a.batch * H * W
+        if "cv" in a.ops:
+            cases.append(("cv L%d" % l, lambda p=prv, q=nxt: ops.cost_volume(p, q), n * (2 * C + 81) * es))
+        if "warp" in a.ops and l > 0:
+            cases.append(("warp L%d" % l, lambda p=img, f=flo: ops.warp(p, f, "clamp"), n * (2 * C * es + 8)))
+        if "fused" in a.ops and l > 0:
+            cases.append(("fused L%d" % l, lambda p=prv, q=nxt, f=flo: ops.warp_cost_volume(p, q, f),
+                          n * ((2 * C + 81) * es + 8)))
+    times = {c[0]: [] for c in cases}
+    for name, fn, _ in cases:  # warm-up
+        for _ in range(3):
+            fn()
+    torch.cuda.synchronize()
+    for _ in range(a.rounds):
+        for name, fn, _ in cases:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            times[name].append(e0.elapsed_time(e1) / a.iters * 1e3)  # us
+    out = {}
+    for name, fn, nbytes in cases:
+        ts = sorted(times[name])
+        med, mn = ts[len(ts) // 2], ts[0]
+        gbs = nbytes / (med * 1e-6) / 1e9
+        out[name] = {"us_med": med, "us_min": mn, "GBs": gbs, "frac": gbs / PEAK, "bytes": nbytes}
+        print("%-10s med %8.2f us  min %8.2f us  %8.1f GB/s  %5.1f%% of 8 TB/s" % (name, med, mn, gbs, 100 * gbs / PEAK))
+    if a.json:
+        json.dump(out, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
