@@ -20,6 +20,8 @@
 //     transposed through LDS (aliasing the input tiles) and leave as fully
 //     coalesced row stores of TW*81 contiguous floats.
 // HBM-bound by design: algorithmic bytes B*H*W*(2C+81)*4, see DESIGN.md.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace qpwc {
@@ -274,9 +276,25 @@ static int cost_volume_impl(const T* prv, const T* nxt, const float* flo, T* out
     return check_launch("cost_volume_generic_kernel");
 }
 
+int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, int H, int W, int C,
+                            int dtype, int64_t ops, float slope, hipStream_t s);
+
+// QPWC_CV_IMPL=valu forces the LDS-tiled vector kernel (A/B measurements only).
+static bool use_mfma() {
+    static const bool v = [] {
+        const char* e = getenv("QPWC_CV_IMPL");
+        return !(e && e[0] == 'v');
+    }();
+    return v;
+}
+
 int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* out, int B, int H,
                        int W, int C, int r, int layout, int dtype, int64_t ops, float slope,
                        bool fuse, hipStream_t s) {
+    if (!fuse && layout == QPWC_NHWC && r == 4 && use_mfma()) {
+        const int rc = cost_volume_mfma_launch(prv, nxt, out, B, H, W, C, dtype, ops, slope, s);
+        if (rc != 1) return rc;  // 1 = shape not eligible for the matrix-core path
+    }
     if (dtype == QPWC_F32)
         return cost_volume_impl<float>((const float*)prv, (const float*)nxt, (const float*)flo,
                                        (float*)out, B, H, W, C, r, layout, ops, slope, fuse, s);

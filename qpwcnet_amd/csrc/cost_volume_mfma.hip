@@ -1,0 +1,331 @@
+// CostVolume forward on the fp32 matrix cores of gfx950 (MI355X, CDNA4, wave64).
+//
+// Reference semantics: qpwcnet/core/layers.py:72-100 == layers.py:128-132:
+//   out[b,y,x,(dy+4)*9+(dx+4)] = lrelu( mean_c prv[b,y,x,c] * nxt0[b,y+dy,x+dx,c] )
+//
+// The correlation of a 4x4 pixel tile with its 12x12 neighbourhood is nine
+// 16x16 dot-product blocks over C: exactly v_mfma_f32_16x16x4_f32 (exact fp32
+// FMA chains, same rate as the vector ALU but 1 VGPR per operand per 1024 FMAs).
+//   rows  (A operand) = the 16 pixels of one 4x4 block of nxt   (9 blocks / tile)
+//   cols  (B operand) = the 16 pixels of the prv tile
+//   k                 = channels; lane (pixel n = lane&15, slot g = lane>>4) loads
+//                       CPL consecutive channels [step*4*CPL + g*CPL, +CPL) with 16-byte
+//                       loads straight from global/L2 (the 4 lanes of a pixel cover a
+//                       contiguous 16*CPL-byte run: one full 128-B line for CPL = 8),
+//                       and feeds them to CPL successive k-steps.  No LDS staging:
+//                       operands go HBM/L2 -> VGPR -> matrix core.
+// 81 of the 144 products per pixel are wanted (56 %); the other 63 are the price of
+// the dense 16x16 shape and never leave the CU.
+//
+// Result lane (col = pixel p, rows 4g..4g+3) holds 4 x-consecutive neighbours, so
+// each accumulator leaves as ONE ds_write_b128 into a per-wave [16 px][12x12] frame
+// (pixel stride 148 floats: conflict free).  Reading the frame back with the
+// window offset (py,px) yields the 81 channels in output order, and the wave
+// stores whole 4-pixel rows: 324 contiguous floats, 256 B per store instruction.
+//
+// Coarse levels have few pixels and many channels (8x16x256): KS waves of a
+// workgroup split the channel range of one tile (split-K) and their partial
+// frames are summed during the read-back, so every level fills the chip.
+#include <type_traits>
+
+#include "common.h"
+
+namespace qpwc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFramePS = 148;                 // floats per pixel frame (144 + 4 pad)
+constexpr int kFrameFloats = 16 * kFramePS;   // per wave
+constexpr int kRowStep = 4 * kFramePS + 12;   // frame offset of the next tile row (py+1, same px)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size we accept: the load returns 0
+
+// Operand fetch, two stages:
+//  (1) COALESCED raw buffer loads (descriptor in SGPRs + 32-bit lane byte offset +
+//      scalar step offset; offsets beyond the descriptor return zero = the
+//      reference's ZeroPadding2D for free).  Load layout: lane l -> pixel l>>2 of the
+//      4x4 block, quarter q = l&3, so the 4 adjacent lanes of a pixel read 64
+//      contiguous bytes per instruction (the texture addresser merges adjacent lanes
+//      only: with the matrix-core layout, where adjacent lanes are adjacent PIXELS,
+//      every lane was its own L1 access and the kernel was TA-bound);
+//  (2) one ds_bpermute per register moves the data to the matrix-core layout
+//      (lane l -> pixel l&15, k-slot l>>4): source lane 4*(l&15) + (l>>4).
+// Channel order inside a step is whatever falls out (k-slot g, k-step (h,e) <->
+// channel step*CSTEP + 16h + 4g + e for fp32 CPL=8); prv and nxt use the same map,
+// and the sum over channels does not care.
+template <int CPL, typename T>
+struct OperandLoad;
+template <>
+struct OperandLoad<4, float> {
+    static constexpr int NREG = 4, QBYTES = 16;
+    static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff,
+                                               unsigned (&v)[NREG]) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = a[i];
+    }
+    static __device__ __forceinline__ void unpack(const unsigned (&v)[NREG], float (&f)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+    }
+};
+template <>
+struct OperandLoad<8, float> {
+    static constexpr int NREG = 8, QBYTES = 16;
+    static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff,
+                                               unsigned (&v)[NREG]) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 64, soff, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = a[i];
+            v[4 + i] = b[i];
+        }
+    }
+    static __device__ __forceinline__ void unpack(const unsigned (&v)[NREG], float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = __uint_as_float(v[i]);
+    }
+};
+__device__ __forceinline__ void unpack_half2(unsigned w, float& lo, float& hi) {
+    const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&w));
+    lo = f.x;
+    hi = f.y;
+}
+template <>
+struct OperandLoad<4, __half> {
+    static constexpr int NREG = 2, QBYTES = 8;
+    static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff,
+                                               unsigned (&v)[NREG]) {
+        const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        v[0] = a[0];
+        v[1] = a[1];
+    }
+    static __device__ __forceinline__ void unpack(const unsigned (&v)[NREG], float (&f)[4]) {
+        unpack_half2(v[0], f[0], f[1]);
+        unpack_half2(v[1], f[2], f[3]);
+    }
+};
+template <>
+struct OperandLoad<8, __half> {
+    static constexpr int NREG = 4, QBYTES = 16;
+    static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff,
+                                               unsigned (&v)[NREG]) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = a[i];
+    }
+    static __device__ __forceinline__ void unpack(const unsigned (&v)[NREG], float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) unpack_half2(v[i], f[2 * i], f[2 * i + 1]);
+    }
+};
+
+// KS  = waves that split the channels of one tile; WPB = waves per workgroup.
+// `inv_c` > 0 means C is a power of two and mean = sum * (1/C) is exact; otherwise
+// the mean is an IEEE division like the reference's reduce_mean.
+template <typename T, int CPL, int KS, int WPB>
+__global__ __launch_bounds__(64 * WPB, 4) void cost_volume_mfma_kernel(
+    const T* __restrict__ prv, const T* __restrict__ nxt, T* __restrict__ out, int H, int W, int C,
+    int tiles_x, int tiles_y, int n_tiles, int out_pix_stride, float slope, float inv_c) {
+    constexpr int G = WPB / KS;       // tiles per workgroup
+    constexpr int CSTEP = 4 * CPL;    // channels consumed per load step
+    constexpr int ES = sizeof(T);
+    static_assert(WPB % KS == 0, "split-K must divide the workgroup");
+    __shared__ __attribute__((aligned(16))) float frames[WPB * kFrameFloats];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar
+    const int lane = threadIdx.x & 63;
+    const int grp = wave / KS, ks = wave % KS;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x) * G + grp;
+    const bool active = tile < n_tiles;  // wave-uniform
+    const int n = lane & 15, g = lane >> 4;  // matrix-core layout: pixel n, k-slot g
+
+    int tx = 0, ty = 0, b = 0;
+    if (active) {
+        tx = tile % tiles_x;
+        ty = (tile / tiles_x) % tiles_y;
+        b = tile / (tiles_x * tiles_y);
+    }
+    const int x0 = tx * 4, y0 = ty * 4;
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (active) {
+        // One descriptor per operand covering exactly image b: rows above / below the
+        // image fall outside it (negative offsets wrap to >= 2^31) and read as zero;
+        // columns left / right of the image are sent out of range explicitly.
+        const int img_bytes = H * W * C * ES;  // < 2^31, checked on the host
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(prv) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(nxt) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+        using OL = OperandLoad<CPL, T>;
+        constexpr int NREG = OL::NREG;
+        const int tile_off = ((y0 - 4) * W + (x0 - 4)) * C * ES;  // scalar, may be negative
+        // load layout: pixel (ly, lx) = lane>>2 of the block, quarter lane&3
+        const int lp = lane >> 2, ly = lp >> 2, lx = lp & 3;
+        const int lane_off = (ly * W + lx) * C * ES + (lane & 3) * OL::QBYTES;
+        const int perm = (4 * n + g) * 4;  // ds_bpermute byte address of the source lane
+        unsigned off_p = (unsigned)(tile_off + lane_off + (4 * W + 4) * C * ES);
+        if (x0 + lx >= W) off_p = kOob;
+        unsigned off_n[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int xx = x0 - 4 + 4 * j + lx;
+            const bool col_ok = xx >= 0 && xx < W;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned o = (unsigned)(tile_off + lane_off + (4 * i * W + 4 * j) * C * ES);
+                off_n[i][j] = col_ok ? o : kOob;
+            }
+        }
+        const int nsteps = C / CSTEP;
+        const int s_lo = ks * nsteps / KS, s_hi = (ks + 1) * nsteps / KS;
+        for (int s = s_lo; s < s_hi; ++s) {
+            const int soff = s * CSTEP * ES;  // scalar
+            unsigned pr[NREG], nr[3][3][NREG];
+            OL::run(rp, off_p, soff, pr);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) OL::run(rn, off_n[i][j], soff, nr[i][j]);
+            // load layout -> matrix-core layout
+            float pv[CPL], nv[3][3][CPL];
+#pragma unroll
+            for (int q = 0; q < NREG; ++q) pr[q] = (unsigned)__builtin_amdgcn_ds_bpermute(perm, (int)pr[q]);
+            OL::unpack(pr, pv);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                    for (int q = 0; q < NREG; ++q)
+                        nr[i][j][q] = (unsigned)__builtin_amdgcn_ds_bpermute(perm, (int)nr[i][j][q]);
+                    OL::unpack(nr[i][j], nv[i][j]);
+                }
+#pragma unroll
+            for (int t = 0; t < CPL; ++t)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nv[i][j][t], pv[t], acc[i][j],
+                                                                         0, 0, 0);
+        }
+    }
+
+    // ---- accumulators -> frame: lane (pixel p = n, neighbour row g) ----------
+    float* fr = frames + wave * kFrameFloats;
+    {
+        float* dst = fr + n * kFramePS + g * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(dst + 48 * i + 4 * j) = acc[i][j];
+    }
+    if (KS > 1)
+        __syncthreads();
+    else
+        __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered; keep the compiler in line
+
+    // ---- frame window -> 81 channels, whole tile rows of 4 px * 81 floats ----
+    if (!active) return;
+    const float cf = (float)C;
+    const float* f0 = frames + grp * KS * kFrameFloats;
+    T* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;  // scalar
+    const int row_stride = W * out_pix_stride;
+    const bool use_mul = inv_c > 0.f;  // wave-uniform
+    const float scale = use_mul ? inv_c : cf;
+    auto readback = [&](auto use_mul_c) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int e = lane + 64 * s;  // element of the 4 px * 81 row
+        const int epx = e / 81, k = e - 81 * epx;
+        const int ky = k / 9, kx = k - 9 * ky;
+        const bool e_ok = e < 324 && x0 + epx < W;
+        const int foff = epx * kFramePS + epx + ky * 12 + kx;  // window origin (py, px) + (ky, kx)
+        const unsigned goff = (unsigned)(epx * out_pix_stride + k);
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            if (KS > 1 && (row * 6 + s) % KS != ks) continue;  // the KS waves share the 24 items
+            if (e_ok && y0 + row < H) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < KS; ++w) v += f0[w * kFrameFloats + foff + row * kRowStep];
+                v = decltype(use_mul_c)::value ? v * scale : v / scale;
+                st(ob + (int64_t)row * row_stride + goff, lrelu(v, slope));
+            }
+        }
+    }
+    };
+    if (use_mul)
+        readback(std::true_type{});
+    else
+        readback(std::false_type{});
+}
+
+template <typename T, int CPL, int KS>
+static int launch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W, int C, int64_t ops,
+                       float slope, hipStream_t s) {
+    constexpr int WPB = KS <= 4 ? 4 : KS;
+    constexpr int G = WPB / KS;
+    const int tiles_x = (W + 3) / 4, tiles_y = (H + 3) / 4;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    const int64_t nblk = (n_tiles + G - 1) / G;
+    if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * (int64_t)sizeof(T) >= 0x7fffffff ||
+        (int64_t)H * W * ops > INT32_MAX) {
+        set_error("image too large for 32-bit tile indexing");
+        return QPWC_E_SHAPE;
+    }
+    const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;  // exact for powers of two
+    hipLaunchKernelGGL((cost_volume_mfma_kernel<T, CPL, KS, WPB>), dim3((unsigned)nblk),
+                       dim3(64 * WPB), 0, s, prv, nxt, out, H, W, C, tiles_x, tiles_y, (int)n_tiles,
+                       (int)ops, slope, inv_c);
+    return check_launch("cost_volume_mfma_kernel");
+}
+
+template <typename T, int CPL>
+static int dispatch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W, int C, int64_t ops,
+                         float slope, hipStream_t s) {
+    const int64_t n_tiles = (int64_t)((W + 3) / 4) * ((H + 3) / 4) * B;
+    const int nsteps = C / (4 * CPL);
+    // enough waves for ~4 per SIMD on 1024 SIMDs; split channels when tiles are few
+    int ks = 1;
+    while (ks < 8 && n_tiles * ks < 4096 && nsteps % (ks * 2) == 0) ks *= 2;
+    switch (ks) {
+        case 1: return launch_mfma<T, CPL, 1>(prv, nxt, out, B, H, W, C, ops, slope, s);
+        case 2: return launch_mfma<T, CPL, 2>(prv, nxt, out, B, H, W, C, ops, slope, s);
+        case 4: return launch_mfma<T, CPL, 4>(prv, nxt, out, B, H, W, C, ops, slope, s);
+        default: return launch_mfma<T, CPL, 8>(prv, nxt, out, B, H, W, C, ops, slope, s);
+    }
+}
+
+// NHWC, search range 4, C % 16 == 0, 16-byte aligned operands.  Returns 1 if the
+// shape is not eligible (caller falls back to the LDS-tiled vector kernel).
+int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, int H, int W, int C,
+                            int dtype, int64_t ops, float slope, hipStream_t s) {
+    if (C % 16 != 0 || (reinterpret_cast<uintptr_t>(prv) | reinterpret_cast<uintptr_t>(nxt)) % 16)
+        return 1;
+    if (dtype == QPWC_F32) {
+        if (C % 32 == 0)
+            return dispatch_mfma<float, 8>((const float*)prv, (const float*)nxt, (float*)out, B, H, W,
+                                           C, ops, slope, s);
+        return dispatch_mfma<float, 4>((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C,
+                                       ops, slope, s);
+    }
+    if (C % 32 == 0)
+        return dispatch_mfma<__half, 8>((const __half*)prv, (const __half*)nxt, (__half*)out, B, H,
+                                        W, C, ops, slope, s);
+    return dispatch_mfma<__half, 4>((const __half*)prv, (const __half*)nxt, (__half*)out, B, H, W, C,
+                                    ops, slope, s);
+}
+
+}  // namespace qpwc

@@ -1,0 +1,24 @@
+#!/bin/bash
+# PMC counter passes with rocprofv3 (counters in their own runs, no trace domains
+# besides --kernel-trace).  Usage: tools/pmc.sh <tag> -- <program> [args...]
+# Results: gpurun_out/pmc_<tag>/<pass>/.../*_counter_collection.csv
+set -u
+tag=$1; shift; shift
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/pmc_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+passes=(
+ "A:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES"
+ "B:SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
+ "C:TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum"
+ "D:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+ "E:FETCH_SIZE"
+ "F:WRITE_SIZE"
+ "G:GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"
+)
+for p in "${passes[@]}"; do
+  name=${p%%:*}; ctrs=${p#*:}
+  timeout -k 10 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out/$name" -- "$@" > "$out/$name.log" 2>&1 || echo "pass $name failed (see $out/$name.log)"
+done
+echo "pmc passes done -> $out"
