@@ -26,6 +26,8 @@
 // Coarse levels have few pixels and many channels (8x16x256): KS waves of a
 // workgroup split the channel range of one tile (split-K) and their partial
 // frames are summed during the read-back, so every level fills the chip.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -272,6 +274,162 @@ __global__ __launch_bounds__(64 * WPB, 4) void cost_volume_mfma_kernel(
         readback(std::false_type{});
 }
 
+// ---------------------------------------------------------------------------
+// Workgroup-shared variant for levels with many tiles (fp32, C % 32 == 0):
+// 4 waves own an 8x8 pixel region (2x2 tiles).  The 16 nxt blocks of its 16x16
+// neighbourhood and the 4 prv blocks are staged ONCE per 32-channel step into
+// LDS (5 block loads per tile instead of 10, every load a full 128-B line per 8
+// lanes), and each wave reads its 10 blocks back directly in matrix-core layout
+// with ds_read_b128 -- no ds_bpermute.  LDS image: block-major, pixel = 128 B,
+// 16-byte chunk c of pixel n stored at chunk c ^ (n >> 1): conflict-free for the
+// staging writes (8 lanes = one pixel) and for the operand reads (16 lanes = 16
+// pixels of one chunk).  The per-wave output frames alias the staging area.
+constexpr int kRegBlocks = 20;                       // 16 nxt + 4 prv
+constexpr int kRegStageBytes = kRegBlocks * 2048;    // 32 channels fp32 per step
+constexpr int kRegLdsBytes = kRegStageBytes > 4 * kFrameFloats * 4 ? kRegStageBytes : 4 * kFrameFloats * 4;
+
+__global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
+    const float* __restrict__ prv, const float* __restrict__ nxt, float* __restrict__ out, int H, int W,
+    int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c) {
+    __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytes];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int region = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int rx = region % regs_x, ry = (region / regs_x) % regs_y, b = region / (regs_x * regs_y);
+    const int X0 = rx * 8, Y0 = ry * 8;
+
+    const int img_bytes = H * W * C * 4;  // < 2^31, checked on the host
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(prv) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(nxt) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+
+    // ---- staging map: piece idx = it*256 + tid -> block 2*it + (tid>>7), pixel, chunk
+    const int hi = tid >> 7, within = tid & 127, sn = within >> 3, sc = within & 7;
+    const int spy = sn >> 2, spx = sn & 3;
+    const int lds_w = hi * 2048 + sn * 128 + ((sc ^ (sn >> 1)) << 4);  // + it*4096
+    unsigned goff[10];
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        int y, x;
+        if (it < 8) {  // nxt block (bi, bj) of the 4x4 block grid at (Y0-4, X0-4)
+            const int bi = it >> 1, bj = 2 * (it & 1) + hi;
+            y = Y0 - 4 + 4 * bi + spy;
+            x = X0 - 4 + 4 * bj + spx;
+        } else {       // prv tile (ti, tj)
+            const int ti = it - 8, tj = hi;
+            y = Y0 + 4 * ti + spy;
+            x = X0 + 4 * tj + spx;
+        }
+        const bool col_ok = x >= 0 && x < W;  // rows outside the image fall out of the descriptor
+        goff[it] = col_ok ? (unsigned)((y * W + x) * C * 4 + sc * 16) : kOob;
+    }
+
+    // ---- operand map (matrix-core layout): lane = pixel n, k-slot g ------------
+    const int n = lane & 15, g = lane >> 4;
+    const int ti = wave >> 1, tj = wave & 1;
+    const int lds_r = n * 128;  // + block*2048 + ((4u+g) ^ (n>>1))*16
+    const int sw = n >> 1;
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = C / 32;
+    for (int s = 0; s < nsteps; ++s) {
+        const int soff = s * 128;
+        u32x4 st[10];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
+#pragma unroll
+        for (int it = 8; it < 10; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[it], soff, 0);
+        if (s > 0) __syncthreads();  // previous step's operand reads are done
+#pragma unroll
+        for (int it = 0; it < 10; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = st[it];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int coff = (((4 * u + g) ^ sw) << 4) + lds_r;
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(smem + (16 + wave) * 2048 + coff);
+            f32x4 nv[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    nv[i][j] = *reinterpret_cast<const f32x4*>(smem + ((ti + i) * 4 + tj + j) * 2048 + coff);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nv[i][j][t], pv[t], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // staging area becomes the four output frames
+
+    float* fr = reinterpret_cast<float*>(smem) + wave * kFrameFloats;
+    {
+        float* dst = fr + n * kFramePS + g * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(dst + 48 * i + 4 * j) = acc[i][j];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
+    if (x0 >= W || y0 >= H) return;
+    const bool use_mul = inv_c > 0.f;
+    const float scale = use_mul ? inv_c : (float)C;
+    float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
+    const int row_stride = W * out_pix_stride;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int e = lane + 64 * s;
+        const int epx = e / 81, k = e - 81 * epx;
+        const int ky = k / 9, kx = k - 9 * ky;
+        const bool e_ok = e < 324 && x0 + epx < W;
+        const int foff = epx * kFramePS + epx + ky * 12 + kx;
+        const unsigned go = (unsigned)(epx * out_pix_stride + k);
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            if (e_ok && y0 + row < H) {
+                float v = fr[foff + row * kRowStep];
+                v = use_mul ? v * scale : v / scale;
+                ob[(int64_t)row * row_stride + go] = lrelu(v, slope);
+            }
+        }
+    }
+}
+
+static int launch_lds(const float* prv, const float* nxt, float* out, int B, int H, int W, int C,
+                      int64_t ops, float slope, hipStream_t s) {
+    const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
+    const int64_t nblk = (int64_t)regs_x * regs_y * B;
+    if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * 4 >= 0x7fffffff ||
+        (int64_t)H * W * ops > INT32_MAX) {
+        set_error("image too large for 32-bit tile indexing");
+        return QPWC_E_SHAPE;
+    }
+    const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
+    hipLaunchKernelGGL(cost_volume_mfma_lds_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
+                       H, W, C, regs_x, regs_y, (int)ops, slope, inv_c);
+    return check_launch("cost_volume_mfma_lds_kernel");
+}
+
+// QPWC_CV_LDS=0 disables the workgroup-shared variant (A/B measurements only).
+static bool use_lds() {
+    static const bool v = [] {
+        const char* e = getenv("QPWC_CV_LDS");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 template <typename T, int CPL, int KS>
 static int launch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W, int C, int64_t ops,
                        float slope, hipStream_t s) {
@@ -315,6 +473,9 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
     if (C % 16 != 0 || (reinterpret_cast<uintptr_t>(prv) | reinterpret_cast<uintptr_t>(nxt)) % 16)
         return 1;
     if (dtype == QPWC_F32) {
+        // many tiles: share the staged neighbourhood across a workgroup
+        if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 1024 && use_lds())
+            return launch_lds((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C, ops, slope, s);
         if (C % 32 == 0)
             return dispatch_mfma<float, 8>((const float*)prv, (const float*)nxt, (float*)out, B, H, W,
                                            C, ops, slope, s);
