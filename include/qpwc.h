@@ -116,6 +116,30 @@ int qpwc_epe_workspace_floats(void);
 int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* workspace,
                  int B, int H, int W, int layout, void* stream);
 
+/* ---- OptFlow block, the step right after the cost volume at every level
+ * (reference qpwcnet/core/non_layers.py:213-273) ---------- */
+
+/* Depthwise half of SeparableConv2D(3x3, 'same', depth_multiplier 1, no depthwise
+ * bias) (non_layers.py:223-231): out[b,y,x,c] = sum_{ky,kx} w[c,ky,kx] * in0[b,y+ky-1,x+kx-1,c],
+ * in0 = (mish_on_load ? Mish(in) : in) inside the image and 0 outside.
+ * `in` is the channel-wise concatenation of n_src (1..3) channels-last fp32 sources:
+ * source i contributes src_channels[i] channels read at src[i] + pixel*src_pixel_stride[i]
+ * (elements) -- Flow/UpFlow's concat([cost, prv, flo]) (non_layers.py:336-338,381-385) is
+ * never materialised.  weight: (C,3,3) fp32, C = sum(src_channels); out: (B,H,W,C) dense. */
+int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
+                       const int64_t* src_pixel_stride, int n_src, int mish_on_load,
+                       const void* weight, void* out, int B, int H, int W, void* stream);
+
+/* Tail of OptFlow.__call__ (non_layers.py:238-254, 268-273) on the 16-channel
+ * pre-activation output z (B,H,W,16) of the last SeparableConv's pointwise conv:
+ *   flow = scale * conv3x3_{16->2, no bias, 'same'}( BN( Mish( W1 * Mish(z) + b1 ) ) )
+ * params (device fp32, qpwc_flow_head_param_floats() = 592 floats):
+ *   w1[16][16] (out,in) | b1[16] | bn_scale[16] | bn_shift[16] | wf[3][3][16][2] (ky,kx,in,out)
+ * with bn_scale = gamma/sqrt(var+eps), bn_shift = beta - mean*bn_scale.  out: (B,H,W,2). */
+int qpwc_flow_head_param_floats(void);
+int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W,
+                       float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

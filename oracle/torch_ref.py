@@ -87,3 +87,29 @@ def tf_warp(img, flow):
 def epe_error(y_true, y_pred):
     """qpwcnet/app/optical_flow/train.py:247-253 (channels_last)."""
     return torch.linalg.vector_norm(y_true - y_pred, ord=2, dim=-1).mean()
+
+
+def mish(x):
+    """qpwcnet/core/mish.py:27-28."""
+    return x * torch.tanh(F.softplus(x))
+
+
+def depthwise3x3(sources, weight, mish_on_load=False):
+    """Depthwise half of SeparableConv2D(3x3,'same') (qpwcnet/core/non_layers.py:223-231)
+    on concat(sources) (non_layers.py:336-338): NHWC in, NHWC out; weight (C,1,3,3)."""
+    x = torch.cat(list(sources), dim=3)
+    if mish_on_load:
+        x = mish(x)
+    y = F.conv2d(x.permute(0, 3, 1, 2), weight.reshape(-1, 1, 3, 3), None, padding=1, groups=x.shape[3])
+    return y.permute(0, 2, 3, 1)
+
+
+def flow_head(z, w1, b1, gamma, beta, mean, var, eps, wf, scale):
+    """Tail of OptFlow.__call__ (qpwcnet/core/non_layers.py:238-254, 268-273) on the
+    pre-activation output z (B,H,W,16) of the last pointwise conv."""
+    x = mish(z).permute(0, 3, 1, 2)
+    x = mish(F.conv2d(x, w1, b1))
+    x = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps) * gamma.view(1, -1, 1, 1) \
+        + beta.view(1, -1, 1, 1)
+    f = F.conv2d(x, wf, None, padding=1)
+    return (scale * f).permute(0, 2, 3, 1)

@@ -24,6 +24,7 @@ SYMBOLS = (
     "qpwc_version", "qpwc_last_error", "qpwc_strerror",
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
+    "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd",
 )
 
 _lib = None
@@ -76,6 +77,13 @@ def lib():
     L.qpwc_epe_workspace_floats.restype = ci
     L.qpwc_epe_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.qpwc_epe_fwd.restype = ci
+    L.qpwc_dwconv3x3_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(i64),
+                                     ci, ci, vp, vp, ci, ci, ci, vp]
+    L.qpwc_dwconv3x3_fwd.restype = ci
+    L.qpwc_flow_head_param_floats.argtypes = []
+    L.qpwc_flow_head_param_floats.restype = ci
+    L.qpwc_flow_head_fwd.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp]
+    L.qpwc_flow_head_fwd.restype = ci
     _lib = L
     return L
 

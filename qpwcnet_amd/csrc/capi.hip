@@ -35,6 +35,11 @@ int epe_workspace_floats();
 int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int H, int W,
                int layout, hipStream_t s);
 
+int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
+                     int act, const void* weight, void* out, int B, int H, int W, hipStream_t s);
+int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
+                     hipStream_t s);
+
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -175,6 +180,45 @@ int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* w
         return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte aligned");
     return epe_launch((const float*)y_true, (const float*)y_pred, (float*)out_mean,
                       (float*)workspace, B, H, W, layout, (hipStream_t)stream);
+}
+
+int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
+                       const int64_t* src_pixel_stride, int n_src, int mish_on_load,
+                       const void* weight, void* out, int B, int H, int W, void* stream) {
+    if (!src || !src_channels || !src_pixel_stride || !weight || !out)
+        return fail(QPWC_E_NULL, "null pointer argument");
+    if (n_src < 1 || n_src > 3) return fail(QPWC_E_SHAPE, "n_src %d outside [1,3]", n_src);
+    if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
+    int64_t C = 0;
+    for (int i = 0; i < n_src; ++i) {
+        if (!src[i]) return fail(QPWC_E_NULL, "null source %d", i);
+        if (src_channels[i] <= 0 || src_pixel_stride[i] < src_channels[i])
+            return fail(QPWC_E_STRIDE, "source %d: %d channels at pixel stride %lld", i,
+                        src_channels[i], (long long)src_pixel_stride[i]);
+        if ((uintptr_t)src[i] % 4) return fail(QPWC_E_ALIGN, "source %d not 4-byte aligned", i);
+        C += src_channels[i];
+    }
+    if ((uintptr_t)out % 4 || (uintptr_t)weight % 4) return fail(QPWC_E_ALIGN, "pointer not 4-byte aligned");
+    const size_t n_out = (size_t)B * H * W * C * 4;
+    for (int i = 0; i < n_src; ++i)
+        if (overlaps(out, n_out, src[i], (size_t)B * H * W * src_pixel_stride[i] * 4))
+            return fail(QPWC_E_ALIAS, "out overlaps source %d", i);
+    if ((int64_t)W * C > INT32_MAX) return fail(QPWC_E_SHAPE, "row too long");
+    return dwconv3x3_launch(src, src_channels, src_pixel_stride, n_src, mish_on_load, weight, out, B,
+                            H, W, (hipStream_t)stream);
+}
+
+int qpwc_flow_head_param_floats(void) { return 592; }
+
+int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W, float scale,
+                       void* stream) {
+    if (!z || !params || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
+    if ((uintptr_t)z % 16 || (uintptr_t)out % 8 || (uintptr_t)params % 4)
+        return fail(QPWC_E_ALIGN, "z must be 16-byte, out 8-byte aligned");
+    if (overlaps(out, (size_t)B * H * W * 8, z, (size_t)B * H * W * 64))
+        return fail(QPWC_E_ALIAS, "out overlaps z");
+    return flow_head_launch(z, params, out, B, H, W, scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,223 @@
+// OptFlow block pieces for gfx950: the step right after the
+// cost volume at every level (reference: qpwcnet/core/non_layers.py:213-273).
+//
+//   SeparableConv2D(3x3, 'same') = depthwise 3x3 (no bias) -> pointwise 1x1 (+bias) -> Mish
+//
+// dwconv3x3: the depthwise half, bandwidth-bound (read C, write C floats per pixel).
+//   * up to three channels-last SOURCES are read as one virtual concatenation, so
+//     Flow/UpFlow's concat([cost, prv, flo]) (non_layers.py:336-338, 381-385) is never
+//     materialised;
+//   * optional Mish on load: the previous layer's activation is applied to the
+//     pre-activation pointwise output while it is read (zero padding applies to the
+//     activated tensor, as in the reference where Mish precedes the next 'same' conv);
+//   * lane = one channel, consecutive lanes = consecutive channels of a pixel: every
+//     wave load/store is a contiguous 256-byte run; a thread walks a strip of rows with
+//     a 3x3 register window (3 loads per output).
+// The pointwise half is a plain GEMM and stays on the library (MFMA through rocBLAS).
+//
+// flow_head: Mish -> 1x1 conv 16->16 + bias -> Mish -> BatchNorm(inference) -> 3x3 conv
+// 16->2 (no bias) -> * scale   (non_layers.py:238-254, 268-273) in one launch; the
+// normalised 16-channel tile (+1 halo, zero outside the image) lives in LDS.
+#include "common.h"
+
+namespace qpwc {
+
+// mish(x) = x * tanh(softplus(x)) = x * t / (t + 2),  t = e^x (e^x + 2); x > 20 -> x
+// (torch's softplus threshold).  ~2 ulp with the fast exp/div.
+__device__ __forceinline__ float mishf(float x) {
+    const float e = __expf(fminf(x, 20.0f));
+    const float t = e * (e + 2.0f);
+    const float m = x * __fdividef(t, t + 2.0f);
+    return x > 20.0f ? x : m;
+}
+
+struct DwSrc {
+    const float* ptr[3];
+    int ch[3];          // channels taken from each source (0 = unused)
+    int64_t stride[3];  // floats per pixel of each source
+};
+
+constexpr int kDwRows = 8;  // rows per thread strip
+
+template <bool ACT>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* __restrict__ weight,
+                                                        float* __restrict__ out, int H, int W, int C,
+                                                        int strips) {
+    // flat index over (x, c) of one row strip
+    const int64_t rowlen = (int64_t)W * C;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rowlen) return;
+    const int x = (int)(idx / C), c = (int)(idx - (int64_t)x * C);
+    const int strip = blockIdx.y % strips, b = blockIdx.y / strips;
+    const int y0 = strip * kDwRows;
+
+    // which source holds channel c
+    const float* p;
+    int64_t ps;
+    int cc;
+    if (c < src.ch[0]) {
+        p = src.ptr[0]; ps = src.stride[0]; cc = c;
+    } else if (c < src.ch[0] + src.ch[1]) {
+        p = src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
+    } else {
+        p = src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
+    }
+    p += (int64_t)b * H * W * ps + cc;
+
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = weight[c * 9 + k];
+
+    const bool xl = x > 0, xr = x + 1 < W;
+    auto load_row = [&](int y, float (&r)[3]) {
+        r[0] = r[1] = r[2] = 0.0f;
+        if (y >= 0 && y < H) {
+            const float* q = p + ((int64_t)y * W + x) * ps;
+            r[1] = q[0];
+            if (xl) r[0] = q[-ps];
+            if (xr) r[2] = q[ps];
+            if (ACT) {
+                r[1] = mishf(r[1]);
+                if (xl) r[0] = mishf(r[0]);
+                if (xr) r[2] = mishf(r[2]);
+            }
+        }
+    };
+    float r0[3], r1[3], r2[3];
+    load_row(y0 - 1, r0);
+    load_row(y0, r1);
+    float* o = out + ((int64_t)(b * H + y0) * W + x) * C + c;
+    const int yend = y0 + kDwRows < H ? y0 + kDwRows : H;
+    for (int y = y0; y < yend; ++y) {
+        load_row(y + 1, r2);
+        float a = w[0] * r0[0];
+        a = fmaf(w[1], r0[1], a);
+        a = fmaf(w[2], r0[2], a);
+        a = fmaf(w[3], r1[0], a);
+        a = fmaf(w[4], r1[1], a);
+        a = fmaf(w[5], r1[2], a);
+        a = fmaf(w[6], r2[0], a);
+        a = fmaf(w[7], r2[1], a);
+        a = fmaf(w[8], r2[2], a);
+        *o = a;
+        o += rowlen;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r0[k] = r1[k];
+            r1[k] = r2[k];
+        }
+    }
+}
+
+int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
+                     int act, const void* weight, void* out, int B, int H, int W, hipStream_t s) {
+    DwSrc d;
+    int C = 0;
+    for (int i = 0; i < 3; ++i) {
+        d.ptr[i] = i < n_src ? (const float*)srcs[i] : nullptr;
+        d.ch[i] = i < n_src ? chans[i] : 0;
+        d.stride[i] = i < n_src ? strides[i] : 0;
+        C += d.ch[i];
+    }
+    const int strips = (H + kDwRows - 1) / kDwRows;
+    const int64_t rowlen = (int64_t)W * C;
+    const dim3 grid((unsigned)((rowlen + 255) / 256), (unsigned)(strips * B));
+    if (act)
+        hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, dim3(256), 0, s, d, (const float*)weight,
+                           (float*)out, H, W, C, strips);
+    else
+        hipLaunchKernelGGL(dwconv3x3_kernel<false>, grid, dim3(256), 0, s, d, (const float*)weight,
+                           (float*)out, H, W, C, strips);
+    return check_launch("dwconv3x3_kernel");
+}
+
+// ---------------------------------------------------------------------------
+// flow head.  params (device, fp32): w1[16][16] (out,in) | b1[16] | bn_scale[16] |
+// bn_shift[16] | wf[3][3][16][2] (ky,kx,in,out)   = 256+16+16+16+288 = 592 floats
+constexpr int kFhC = 16;
+constexpr int kFhTile = 16;
+constexpr int kFhParams = 592;
+
+__global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict__ z,
+                                                        const float* __restrict__ params,
+                                                        float* __restrict__ out, int H, int W,
+                                                        int tiles_x, int tiles_y, float scale) {
+    constexpr int TW = kFhTile + 2;
+    __shared__ __attribute__((aligned(16))) float hs[TW * TW * kFhC];  // 18*18*16*4 = 20.7 KB
+    __shared__ float ps[kFhParams];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int x0 = tx * kFhTile, y0 = ty * kFhTile;
+    for (int i = tid; i < kFhParams; i += 256) ps[i] = params[i];
+    __syncthreads();
+    const float* w1 = ps;
+    const float* b1 = ps + 256;
+    const float* bs = ps + 272;
+    const float* bt = ps + 288;
+    const float* wf = ps + 304;
+    const float* zb = z + (int64_t)b * H * W * kFhC;
+
+    // stage h3 = BN(mish(W1 mish(z) + b1)) for the tile + 1 halo; zero outside the image
+    for (int p = tid; p < TW * TW; p += 256) {
+        const int ly = p / TW, lx = p - ly * TW;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        float h[kFhC];
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const float4* q = reinterpret_cast<const float4*>(zb + ((int64_t)gy * W + gx) * kFhC);
+            float a[kFhC];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = q[i];
+                a[4 * i] = mishf(v.x); a[4 * i + 1] = mishf(v.y);
+                a[4 * i + 2] = mishf(v.z); a[4 * i + 3] = mishf(v.w);
+            }
+#pragma unroll
+            for (int o = 0; o < kFhC; ++o) {
+                float s = b1[o];
+#pragma unroll
+                for (int i = 0; i < kFhC; ++i) s = fmaf(w1[o * kFhC + i], a[i], s);
+                h[o] = fmaf(mishf(s), bs[o], bt[o]);
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < kFhC; ++o) h[o] = 0.0f;
+        }
+        float4* d = reinterpret_cast<float4*>(hs + p * kFhC);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = make_float4(h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+    }
+    __syncthreads();
+
+    const int lx = tid % kFhTile, ly = tid / kFhTile;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= W || gy >= H) return;
+    float fx = 0.0f, fy = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float4* q = reinterpret_cast<const float4*>(hs + ((ly + ky) * TW + lx + kx) * kFhC);
+            const float* wk = wf + (ky * 3 + kx) * kFhC * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = q[i];
+                fx = fmaf(v.x, wk[(4 * i) * 2], fx);     fy = fmaf(v.x, wk[(4 * i) * 2 + 1], fy);
+                fx = fmaf(v.y, wk[(4 * i + 1) * 2], fx); fy = fmaf(v.y, wk[(4 * i + 1) * 2 + 1], fy);
+                fx = fmaf(v.z, wk[(4 * i + 2) * 2], fx); fy = fmaf(v.z, wk[(4 * i + 2) * 2 + 1], fy);
+                fx = fmaf(v.w, wk[(4 * i + 3) * 2], fx); fy = fmaf(v.w, wk[(4 * i + 3) * 2 + 1], fy);
+            }
+        }
+    float2* o = reinterpret_cast<float2*>(out + ((int64_t)(b * H + gy) * W + gx) * 2);
+    *o = make_float2(scale * fx, scale * fy);
+}
+
+int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
+                     hipStream_t s) {
+    const int tiles_x = (W + kFhTile - 1) / kFhTile, tiles_y = (H + kFhTile - 1) / kFhTile;
+    hipLaunchKernelGGL(flow_head_kernel, dim3((unsigned)(tiles_x * tiles_y * B)), dim3(256), 0, s,
+                       (const float*)z, (const float*)params, (float*)out, H, W, tiles_x, tiles_y, scale);
+    return check_launch("flow_head_kernel");
+}
+
+}  // namespace qpwc

@@ -182,6 +182,40 @@ class OptFlow(_Weighted):
         self.filters = tuple(filters)
         self.scale = scale
 
+    # ---- HIP path: multi-source depthwise kernel (no concat, Mish
+    # fused on load), pointwise convs as library GEMMs, fused flow head ---------------
+    def _prepare_hip(self):
+        if getattr(self, "_hip_ready", False):
+            return
+        self._pw_t, self._pw_b, self._dw = [], [], []
+        for i in range(len(self.filters)):
+            pw = self.p("feat.{}.pointwise.weight".format(i))
+            self._pw_t.append(pw.reshape(pw.shape[0], pw.shape[1]).t().contiguous())
+            self._pw_b.append(self.p("feat.{}.bias".format(i)).contiguous())
+            dw = self.p("feat.{}.depthwise.weight".format(i))
+            self._dw.append(dw.reshape(dw.shape[0], 9).contiguous())
+        self._head = pack_flow_head(self.p("conv.weight"), self.p("conv.bias"), self.p("norm.gamma"),
+                                    self.p("norm.beta"), self.p("norm.mean"), self.p("norm.var"),
+                                    self.BN_EPS, self.p("flow.weight"))
+        self._hip_ready = True
+
+    def can_use_hip(self, sources):
+        return (self.data_format == CHANNELS_LAST and self.filters[-1] == 16 and
+                all(t.is_cuda and t.dtype == torch.float32 for t in sources))
+
+    def from_sources(self, sources):
+        """OptFlow on the virtual concat of `sources` ((B,H,W,Ci) each, channels_last)."""
+        if not self.can_use_hip(sources):
+            return self(torch.cat(list(sources), dim=self.axis))
+        self._prepare_hip()
+        B, H, W = sources[0].shape[:3]
+        scale = self.scale if self.scale is not None else float(H ** 2 + W ** 2) ** 0.5
+        z = None
+        for i in range(len(self.filters)):
+            y = ops.dwconv3x3(sources if i == 0 else [z], self._dw[i], mish_on_load=i > 0)
+            z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1), self._pw_t[i]).view(B, H, W, -1)
+        return ops.flow_head(z, self._head, scale)
+
     def __call__(self, inputs):
         shape = parse_image_shape(inputs, self.data_format)
         scale = self.scale
@@ -201,19 +235,31 @@ class OptFlow(_Weighted):
         return self._fmt(scale * f)
 
 
+def pack_flow_head(w1, b1, gamma, beta, mean, var, eps, wf):
+    """Parameter vector of qpwc_flow_head_fwd (include/qpwc.h): w1[16][16] | b1 | bn_scale |
+    bn_shift | wf[ky][kx][in][out]; BatchNorm folded to scale/shift."""
+    bn_scale = gamma / torch.sqrt(var + eps)
+    bn_shift = beta - mean * bn_scale
+    return torch.cat([w1.reshape(16, 16).reshape(-1), b1.reshape(-1), bn_scale.reshape(-1),
+                      bn_shift.reshape(-1), wf.permute(2, 3, 1, 0).reshape(-1)]).contiguous().float()
+
+
 class Flow(_Weighted):
     """First flow block, qpwcnet/core/non_layers.py:315-338:
     cost = cv(prv, nxt); OptFlow(concat[cost, prv, nxt])."""
 
-    def __init__(self, params, prefix, use_tfa=True, *args, **kwargs):
+    def __init__(self, params, prefix, use_tfa=True, hip_optflow=True, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
         self.flow = OptFlow(params, prefix + "flow.", data_format=self.data_format)
         cls = CostVolumeV2 if use_tfa else CostVolume
         self.cost_volume = cls(data_format=self.data_format)
+        self.hip_optflow = bool(hip_optflow)
 
     def __call__(self, inputs):
         prv, nxt = inputs
         cost = self.cost_volume((prv, nxt))
+        if self.hip_optflow:
+            return self.flow.from_sources((cost, prv, nxt))
         feat = torch.cat([cost, prv, nxt], dim=self.axis)
         return self.flow(feat)
 
@@ -225,9 +271,10 @@ class UpFlow(_Weighted):
     fused=True (channels_last only) produces the same ``feat`` with one
     warp+cost-volume launch writing straight into the concat buffer."""
 
-    def __init__(self, params, prefix, use_tfa=True, fused=False, *args, **kwargs):
+    def __init__(self, params, prefix, use_tfa=True, fused=False, hip_optflow=True, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
         self._config = {"use_tfa": use_tfa}
+        self.hip_optflow = bool(hip_optflow)
         self.flow = OptFlow(params, prefix + "flow.", data_format=self.data_format)
         self.warp = WarpV2(data_format=self.data_format)
         cls = CostVolumeV2 if use_tfa else CostVolume
@@ -238,10 +285,12 @@ class UpFlow(_Weighted):
         prv, nxt, flo = inputs
         if self.fused:
             feat = self._fused_feat(prv, nxt, flo)
-        else:
-            nxt_w = self.warp((nxt, flo))
-            cost = self.cost_volume((prv, nxt_w))
-            feat = torch.cat([cost, prv, flo], dim=self.axis)
+            return self.flow(feat)
+        nxt_w = self.warp((nxt, flo))
+        cost = self.cost_volume((prv, nxt_w))
+        if self.hip_optflow:
+            return self.flow.from_sources((cost, prv, flo))
+        feat = torch.cat([cost, prv, flo], dim=self.axis)
         return self.flow(feat)
 
     def _fused_feat(self, prv, nxt, flo):

@@ -253,3 +253,64 @@ def epe(y_true, y_pred, data_format=CHANNELS_LAST):
                             layout, _stream(a))
     _hip.check(rc)
     return out
+
+
+def dwconv3x3(sources, weight, mish_on_load=False):
+    """Depthwise 3x3 'same' convolution over the channel-wise concatenation of 1..3
+    channels-last fp32 sources (each (B,H,W,Ci), last dim contiguous) -- the depthwise
+    half of OptFlow's SeparableConv2D (qpwcnet/core/non_layers.py:223-231) without ever
+    building Flow/UpFlow's concat (non_layers.py:336-338, 381-385).
+    weight: (C,1,3,3) or (C,3,3) with C = sum(Ci).  -> (B,H,W,C)."""
+    import ctypes
+    if not 1 <= len(sources) <= 3:
+        raise ValueError("dwconv3x3 takes 1..3 sources")
+    B, H, W = sources[0].shape[:3]
+    chans, strides, ptrs, keep = [], [], [], []
+    for i, t in enumerate(sources):
+        _check_tensor("source %d" % i, t)
+        if t.dtype != torch.float32:
+            raise ValueError("dwconv3x3 is fp32 only")
+        if tuple(t.shape[:3]) != (B, H, W):
+            raise ValueError("sources must share B,H,W")
+        if t.stride(3) != 1 or t.stride(1) != W * t.stride(2) or t.stride(0) != H * t.stride(1):
+            t = t.contiguous()
+        keep.append(t)
+        chans.append(t.shape[3])
+        strides.append(t.stride(2))
+        ptrs.append(t.data_ptr())
+    C = sum(chans)
+    w = weight.reshape(-1, 9)
+    if w.shape[0] != C or w.dtype != torch.float32 or not w.is_cuda:
+        raise ValueError("weight must be fp32 (C,3,3) on the device with C = {}".format(C))
+    w = w.contiguous()
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=keep[0].device)
+    n = len(keep)
+    c_ptrs = (ctypes.c_void_p * n)(*ptrs)
+    c_ch = (ctypes.c_int * n)(*chans)
+    c_st = (ctypes.c_int64 * n)(*strides)
+    with torch.cuda.device(out.device), _timed("dwconv3x3", (B, H, W, C)):
+        rc = _hip.lib().qpwc_dwconv3x3_fwd(c_ptrs, c_ch, c_st, n, int(bool(mish_on_load)),
+                                            w.data_ptr(), out.data_ptr(), B, H, W, _stream(out))
+    _hip.check(rc)
+    return out
+
+
+def flow_head(z, params, scale):
+    """Tail of OptFlow (non_layers.py:238-254, 268-273) on the pre-activation 16-channel
+    tensor z (B,H,W,16): scale * conv3x3(BN(Mish(W1 Mish(z) + b1))) -> (B,H,W,2).
+    params: packed fp32 vector, see include/qpwc.h / non_layers.pack_flow_head."""
+    _check_tensor("z", z)
+    if z.dtype != torch.float32 or z.shape[3] != 16 or not z.is_contiguous():
+        raise ValueError("z must be a dense fp32 (B,H,W,16) tensor")
+    L = _hip.lib()
+    if params.numel() != L.qpwc_flow_head_param_floats() or params.dtype != torch.float32 or \
+            not params.is_cuda or not params.is_contiguous():
+        raise ValueError("params must be a dense fp32 device vector of {} floats".format(
+            L.qpwc_flow_head_param_floats()))
+    B, H, W, _ = z.shape
+    out = torch.empty((B, H, W, 2), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device), _timed("flow_head", (B, H, W, 16)):
+        rc = L.qpwc_flow_head_fwd(z.data_ptr(), params.data_ptr(), out.data_ptr(), B, H, W,
+                                  float(scale), _stream(z))
+    _hip.check(rc)
+    return out

@@ -67,7 +67,7 @@ class QpwcNet:
     multi-scale flows when ``train`` (pwcnet.py:237-239) else the final flow only."""
 
     def __init__(self, weights, train=True, input_shape=(256, 512), data_format=None,
-                 use_tfa=True, device="cuda", dtype=torch.float32, fused=False):
+                 use_tfa=True, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True):
         self.data_format = image_data_format() if data_format is None else data_format
         self.axis = get_axis(self.data_format)
         self.train = train
@@ -86,9 +86,10 @@ class QpwcNet:
                     for i in range(len(ENC_FILTERS))]
         self.dec = [UpConv(self.params, "dec.{}.".format(i), data_format=df)
                     for i in range(len(DEC_FILTERS))]
-        self.flow = Flow(self.params, "flow.", use_tfa=use_tfa, data_format=df)
+        self.flow = Flow(self.params, "flow.", use_tfa=use_tfa, hip_optflow=hip_optflow, data_format=df)
         self.upflows = [UpFlow(self.params, "upflow.{}.".format(i), use_tfa=use_tfa, fused=fused,
-                               data_format=df) for i in range(len(DEC_FILTERS))]
+                               hip_optflow=hip_optflow, data_format=df)
+                        for i in range(len(DEC_FILTERS))]
 
     def __call__(self, inputs):
         exp = (self.input_shape + (6,)) if self.data_format == CHANNELS_LAST \
@@ -110,10 +111,10 @@ class QpwcNet:
 
 
 def build_flower(train=True, input_shape=(256, 512), data_format=None, use_tfa=True,
-                 weights=None, device="cuda", dtype=torch.float32, fused=False):
+                 weights=None, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True):
     """pwcnet.py:210-244.  ``weights``: flat dict from ``synth.make_weights`` (default:
     seed 42), since no checkpoint ships with the reference."""
     if weights is None:
         weights = make_weights(42, input_shape)
     return QpwcNet(weights, train=train, input_shape=input_shape, data_format=data_format,
-                   use_tfa=use_tfa, device=device, dtype=dtype, fused=fused)
+                   use_tfa=use_tfa, device=device, dtype=dtype, fused=fused, hip_optflow=hip_optflow)

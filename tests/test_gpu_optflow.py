@@ -1,0 +1,99 @@
+"""GPU suite: the OptFlow pieces -- multi-source depthwise 3x3 and
+the fused flow head -- against the torch-CPU restatement of qpwcnet/core/non_layers.py:213-273."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_ref, torch_ref
+from qpwcnet_amd import non_layers, ops, synth
+from qpwcnet_amd.pwcnet import build_flower
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def _rand(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+@pytest.mark.parametrize("chans", [(81, 32, 2), (81, 256, 256), (128,), (7, 3)])
+@pytest.mark.parametrize("hw", [(8, 16), (19, 37)])
+@pytest.mark.parametrize("act", [False, True])
+def test_dwconv3x3_multi_source(chans, hw, act):
+    rng = np.random.default_rng(sum(chans) + hw[0])
+    H, W = hw
+    srcs = [_rand(rng, 2, H, W, c) for c in chans]
+    w = _rand(rng, sum(chans), 1, 3, 3)
+    ref = torch_ref.depthwise3x3(srcs, w, act)
+    out = ops.dwconv3x3([s.to(DEV) for s in srcs], w.to(DEV), mish_on_load=act).cpu()
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out, ref, rtol=0, atol=2e-5)
+
+
+def test_dwconv3x3_strided_source_view():
+    """A source may be a channel slice of a wider channels-last buffer (pixel stride > channels)."""
+    rng = np.random.default_rng(3)
+    big = _rand(rng, 2, 12, 10, 40)
+    w = _rand(rng, 16, 1, 3, 3)
+    ref = torch_ref.depthwise3x3([big[..., 8:24]], w)
+    out = ops.dwconv3x3([big.to(DEV)[..., 8:24]], w.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, rtol=0, atol=2e-5)
+
+
+def test_dwconv3x3_errors():
+    x = torch.zeros(1, 4, 4, 8, device=DEV)
+    with pytest.raises(ValueError):
+        ops.dwconv3x3([x], torch.zeros(7, 3, 3, device=DEV))
+    with pytest.raises(ValueError):
+        ops.dwconv3x3([x, x, x, x], torch.zeros(32, 3, 3, device=DEV))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.dwconv3x3([x.cpu()], torch.zeros(8, 3, 3))
+
+
+@pytest.mark.parametrize("hw", [(8, 16), (33, 50), (128, 256)])
+def test_flow_head(hw):
+    rng = np.random.default_rng(hw[0])
+    H, W = hw
+    z = _rand(rng, 2, H, W, 16)
+    w1, b1 = _rand(rng, 16, 16, 1, 1) * 0.3, _rand(rng, 16) * 0.1
+    gamma, beta = 1 + 0.1 * _rand(rng, 16), 0.1 * _rand(rng, 16)
+    mean, var = 0.1 * _rand(rng, 16), 1 + 0.2 * torch.rand(16)
+    wf = _rand(rng, 2, 16, 3, 3) * 0.2
+    scale = float(H * H + W * W) ** 0.5
+    ref = torch_ref.flow_head(z, w1, b1, gamma, beta, mean, var, 1e-3, wf, scale)
+    params = non_layers.pack_flow_head(*(t.to(DEV) for t in (w1, b1, gamma, beta, mean, var)), 1e-3,
+                                       wf.to(DEV))
+    out = ops.flow_head(z.to(DEV), params, scale).cpu()
+    # outputs are O(scale): compare relative to the scale factor
+    torch.testing.assert_close(out / scale, ref / scale, rtol=0, atol=2e-5)
+
+
+def test_optflow_block_hip_equals_torch_path():
+    """OptFlow.from_sources (HIP) == OptFlow(concat) (PyTorch convs) == oracle."""
+    hw = (32, 64)
+    weights = synth.make_weights(42, (256, 512))
+    rng = np.random.default_rng(5)
+    cost, prv, flo = _rand(rng, 2, *hw, 81), _rand(rng, 2, *hw, 128), _rand(rng, 2, *hw, 2)
+    params = {k: torch.as_tensor(v).to(DEV) for k, v in weights.items()}
+    of = non_layers.OptFlow(params, "upflow.1.flow.", data_format="channels_last")
+    srcs = [t.to(DEV) for t in (cost, prv, flo)]
+    a = of.from_sources(srcs).cpu()
+    b = of(torch.cat(srcs, dim=3)).cpu()
+    ref = net_ref.RefNet(weights).opt_flow("upflow.1.flow.", torch.cat([cost, prv, flo], dim=3))
+    scale = float(hw[0] ** 2 + hw[1] ** 2) ** 0.5
+    torch.testing.assert_close(a / scale, ref / scale, rtol=0, atol=2e-5)
+    torch.testing.assert_close(b / scale, ref / scale, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("hip_optflow", [False, True])
+def test_full_network_both_optflow_paths(hip_optflow):
+    hw = (64, 128)
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(2, hw[0], hw[1], seed=1234)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV, hip_optflow=hip_optflow)
+    flows = model.predict(pairs)
+    ref = net_ref.RefNet(weights)(pairs)
+    for lvl, (x, y) in enumerate(zip(flows, ref)):
+        e = float(torch_ref.epe_error(x.cpu(), y))
+        assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
