@@ -39,6 +39,7 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
                      int act, const void* weight, void* out, int B, int H, int W, hipStream_t s);
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      hipStream_t s);
+int flow_head_param_floats();
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -208,7 +209,7 @@ int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
                             H, W, (hipStream_t)stream);
 }
 
-int qpwc_flow_head_param_floats(void) { return 592; }
+int qpwc_flow_head_param_floats(void) { return flow_head_param_floats(); }
 
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                        void* stream) {

@@ -11,8 +11,9 @@
 //     pre-activation pointwise output while it is read (zero padding applies to the
 //     activated tensor, as in the reference where Mish precedes the next 'same' conv);
 //   * lane = one channel, consecutive lanes = consecutive channels of a pixel: every
-//     wave load/store is a contiguous 256-byte run; a thread walks a strip of rows with
-//     a 3x3 register window (3 loads per output).
+//     wave load/store is a contiguous 256-byte run; a thread owns 4 consecutive pixels
+//     and walks a strip of rows with a rolling 3x6 register window (1.5 loads and Mish
+//     evaluations per output).
 // The pointwise half is a plain GEMM and stays on the library (MFMA through rocBLAS).
 //
 // flow_head: Mish -> 1x1 conv 16->16 + bias -> Mish -> BatchNorm(inference) -> 3x3 conv
@@ -38,16 +39,21 @@ struct DwSrc {
 };
 
 constexpr int kDwRows = 8;  // rows per thread strip
+constexpr int kDwPx = 4;    // consecutive pixels per thread
 
+// thread = (4 consecutive pixels, 1 channel): per input row it loads 6 values, applies
+// Mish once to each (1.5 evaluations per output instead of 3 for one pixel per thread),
+// and keeps a rolling 3-row window; the raw values of the next row are requested one
+// iteration ahead so that the loop does not wait on a load it has just issued.
 template <bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* __restrict__ weight,
                                                         float* __restrict__ out, int H, int W, int C,
-                                                        int strips) {
-    // flat index over (x, c) of one row strip
-    const int64_t rowlen = (int64_t)W * C;
+                                                        int strips, int wq) {
+    const int64_t rowthreads = (int64_t)wq * C;  // (x-quad, channel) pairs of one row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rowlen) return;
-    const int x = (int)(idx / C), c = (int)(idx - (int64_t)x * C);
+    if (idx >= rowthreads) return;
+    const int xq = (int)(idx / C), c = (int)(idx - (int64_t)xq * C);
+    const int x0 = xq * kDwPx;
     const int strip = blockIdx.y % strips, b = blockIdx.y / strips;
     const int y0 = strip * kDwRows;
 
@@ -68,43 +74,55 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = weight[c * 9 + k];
 
-    const bool xl = x > 0, xr = x + 1 < W;
-    auto load_row = [&](int y, float (&r)[3]) {
-        r[0] = r[1] = r[2] = 0.0f;
-        if (y >= 0 && y < H) {
-            const float* q = p + ((int64_t)y * W + x) * ps;
-            r[1] = q[0];
-            if (xl) r[0] = q[-ps];
-            if (xr) r[2] = q[ps];
-            if (ACT) {
-                r[1] = mishf(r[1]);
-                if (xl) r[0] = mishf(r[0]);
-                if (xr) r[2] = mishf(r[2]);
-            }
-        }
+    bool col_ok[kDwPx + 2];
+#pragma unroll
+    for (int j = 0; j < kDwPx + 2; ++j) col_ok[j] = x0 - 1 + j >= 0 && x0 - 1 + j < W;
+
+    auto load_raw = [&](int y, float (&r)[kDwPx + 2]) {
+        const bool row_ok = y >= 0 && y < H;
+        const float* q = p + ((int64_t)y * W + (x0 - 1)) * ps;
+#pragma unroll
+        for (int j = 0; j < kDwPx + 2; ++j) r[j] = (row_ok && col_ok[j]) ? q[(int64_t)j * ps] : 0.0f;
     };
-    float r0[3], r1[3], r2[3];
-    load_row(y0 - 1, r0);
-    load_row(y0, r1);
-    float* o = out + ((int64_t)(b * H + y0) * W + x) * C + c;
+    auto activate = [&](int y, float (&r)[kDwPx + 2]) {
+        if (!ACT) return;
+        const bool row_ok = y >= 0 && y < H;  // zero padding applies to the ACTIVATED tensor
+#pragma unroll
+        for (int j = 0; j < kDwPx + 2; ++j) r[j] = (row_ok && col_ok[j]) ? mishf(r[j]) : 0.0f;
+    };
+
+    float r0[kDwPx + 2], r1[kDwPx + 2], r2[kDwPx + 2], ahead[kDwPx + 2];
+    load_raw(y0 - 1, r0);
+    load_raw(y0, r1);
+    load_raw(y0 + 1, ahead);
+    activate(y0 - 1, r0);
+    activate(y0, r1);
+    float* o = out + ((int64_t)(b * H + y0) * W + x0) * C + c;
+    const int64_t rowlen = (int64_t)W * C;
     const int yend = y0 + kDwRows < H ? y0 + kDwRows : H;
     for (int y = y0; y < yend; ++y) {
-        load_row(y + 1, r2);
-        float a = w[0] * r0[0];
-        a = fmaf(w[1], r0[1], a);
-        a = fmaf(w[2], r0[2], a);
-        a = fmaf(w[3], r1[0], a);
-        a = fmaf(w[4], r1[1], a);
-        a = fmaf(w[5], r1[2], a);
-        a = fmaf(w[6], r2[0], a);
-        a = fmaf(w[7], r2[1], a);
-        a = fmaf(w[8], r2[2], a);
-        *o = a;
+#pragma unroll
+        for (int j = 0; j < kDwPx + 2; ++j) r2[j] = ahead[j];
+        if (y + 1 < yend) load_raw(y + 2, ahead);  // in flight during this row's arithmetic
+        activate(y + 1, r2);
+#pragma unroll
+        for (int i = 0; i < kDwPx; ++i) {
+            float a = w[0] * r0[i];
+            a = fmaf(w[1], r0[i + 1], a);
+            a = fmaf(w[2], r0[i + 2], a);
+            a = fmaf(w[3], r1[i], a);
+            a = fmaf(w[4], r1[i + 1], a);
+            a = fmaf(w[5], r1[i + 2], a);
+            a = fmaf(w[6], r2[i], a);
+            a = fmaf(w[7], r2[i + 1], a);
+            a = fmaf(w[8], r2[i + 2], a);
+            if (x0 + i < W) o[(int64_t)i * C] = a;
+        }
         o += rowlen;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            r0[k] = r1[k];
-            r1[k] = r2[k];
+        for (int j = 0; j < kDwPx + 2; ++j) {
+            r0[j] = r1[j];
+            r1[j] = r2[j];
         }
     }
 }
@@ -120,14 +138,15 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
         C += d.ch[i];
     }
     const int strips = (H + kDwRows - 1) / kDwRows;
-    const int64_t rowlen = (int64_t)W * C;
-    const dim3 grid((unsigned)((rowlen + 255) / 256), (unsigned)(strips * B));
+    const int wq = (W + kDwPx - 1) / kDwPx;
+    const int64_t rowthreads = (int64_t)wq * C;
+    const dim3 grid((unsigned)((rowthreads + 255) / 256), (unsigned)(strips * B));
     if (act)
         hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, dim3(256), 0, s, d, (const float*)weight,
-                           (float*)out, H, W, C, strips);
+                           (float*)out, H, W, C, strips, wq);
     else
         hipLaunchKernelGGL(dwconv3x3_kernel<false>, grid, dim3(256), 0, s, d, (const float*)weight,
-                           (float*)out, H, W, C, strips);
+                           (float*)out, H, W, C, strips, wq);
     return check_launch("dwconv3x3_kernel");
 }
 
@@ -136,26 +155,25 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
 // bn_shift[16] | wf[3][3][16][2] (ky,kx,in,out)   = 256+16+16+16+288 = 592 floats
 constexpr int kFhC = 16;
 constexpr int kFhTile = 16;
-constexpr int kFhParams = 592;
+constexpr int kFhParams = 592;  // == qpwc_flow_head_param_floats()
 
-__global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict__ z,
+__global__ __launch_bounds__(256, 4) void flow_head_kernel(const float* __restrict__ z,
                                                         const float* __restrict__ params,
                                                         float* __restrict__ out, int H, int W,
                                                         int tiles_x, int tiles_y, float scale) {
     constexpr int TW = kFhTile + 2;
     __shared__ __attribute__((aligned(16))) float hs[TW * TW * kFhC];  // 18*18*16*4 = 20.7 KB
-    __shared__ float ps[kFhParams];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int x0 = tx * kFhTile, y0 = ty * kFhTile;
-    for (int i = tid; i < kFhParams; i += 256) ps[i] = params[i];
-    __syncthreads();
-    const float* w1 = ps;
-    const float* b1 = ps + 256;
-    const float* bs = ps + 272;
-    const float* bt = ps + 288;
-    const float* wf = ps + 304;
+    // parameters are read with compile-time offsets from the (uniform) kernel argument:
+    // scalar loads, the weights sit in SGPRs as FMA operands
+    const float* w1 = params;
+    const float* b1 = params + 256;
+    const float* bs = params + 272;
+    const float* bt = params + 288;
+    const float* wf = params + 304;
     const float* zb = z + (int64_t)b * H * W * kFhC;
 
     // stage h3 = BN(mish(W1 mish(z) + b1)) for the tile + 1 halo; zero outside the image
@@ -211,6 +229,8 @@ __global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict_
     float2* o = reinterpret_cast<float2*>(out + ((int64_t)(b * H + gy) * W + gx) * 2);
     *o = make_float2(scale * fx, scale * fy);
 }
+
+int flow_head_param_floats() { return kFhParams; }
 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      hipStream_t s) {

@@ -67,10 +67,12 @@ class QpwcNet:
     multi-scale flows when ``train`` (pwcnet.py:237-239) else the final flow only."""
 
     def __init__(self, weights, train=True, input_shape=(256, 512), data_format=None,
-                 use_tfa=True, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True):
+                 use_tfa=True, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True,
+                 batch_frames=True):
         self.data_format = image_data_format() if data_format is None else data_format
         self.axis = get_axis(self.data_format)
         self.train = train
+        self.batch_frames = bool(batch_frames)
         self.input_shape = tuple(input_shape)
         self.device = torch.device(device)
         self.dtype = dtype
@@ -97,8 +99,25 @@ class QpwcNet:
         if tuple(inputs.shape[1:]) != exp:
             raise ValueError("expected input shape (B,)+{}, got {}".format(exp, tuple(inputs.shape)))
         img_prv, img_nxt = self.split(inputs)
-        encs_prv, encs_nxt = encoder(self.enc, img_prv, img_nxt, True)
-        decs_prv, decs_nxt = decoder(self.dec, encs_prv, encs_nxt, self.axis, True)
+        if self.batch_frames:
+            # The encoder/decoder weights are shared by both frames (pwcnet.py:145-162,
+            # 179-206): run them once on the 2B stacked frames, then split by views.
+            nb = inputs.shape[0]
+            f = torch.cat([img_prv, img_nxt], dim=0)
+            encs = [f]
+            for l in self.enc:
+                f = l(f)
+                encs.append(f)
+            decs, i = [], -2
+            for l in self.dec:
+                f = torch.cat([l(f), encs[i]], dim=self.axis)
+                i -= 1
+                decs.append(f)
+            encs_prv, encs_nxt = [e[:nb] for e in encs], [e[nb:] for e in encs]
+            decs_prv, decs_nxt = [d[:nb] for d in decs], [d[nb:] for d in decs]
+        else:
+            encs_prv, encs_nxt = encoder(self.enc, img_prv, img_nxt, True)
+            decs_prv, decs_nxt = decoder(self.dec, encs_prv, encs_nxt, self.axis, True)
         outs = flower(self.flow, self.upflows, encs_prv[-1], encs_nxt[-1], decs_prv, decs_nxt,
                       self.data_format, output_multiscale=self.train)
         return outs if self.train else outs[0]

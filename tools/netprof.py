@@ -45,6 +45,7 @@ def main():
     wrap(F, "interpolate", lambda x, **k: "interp %s" % sh(x))
     wrap(F, "batch_norm", lambda x, *r, **k: "bn %s" % sh(x))
     wrap(F, "pad", lambda x, p: "pad %s" % sh(x))
+    wrap(torch, "addmm", lambda b, x, w: "addmm %s @ %s" % (sh(x), sh(w)))
     wrap(torch, "cat", lambda ts, dim=0: "cat " + "+".join(sh(t) for t in ts))
     dev = "cuda:0"
     model = build_flower(True, (256, 512), "channels_last", device=dev, fused=a.fused)
