@@ -43,6 +43,10 @@ def parse_args():
     p.add_argument("--fused", dest="fused", action="store_true", default=False,
                    help="fused warp+cost-volume UpFlow front end")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                   help="f16 = BASELINE configs[4] (fp16 storage / convs, fp32 accumulate in the hot path)")
+    p.add_argument("--dist-backend", default=None,
+                   help="rehearsal only: 'gloo' runs N ranks on ONE GPU (EPE gathered through host memory)")
     p.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the host for cpu_baseline")
     return p.parse_args()
 
@@ -74,7 +78,9 @@ def cpu_baseline(weights, pairs_np, n_pairs, gpu_flows):
 
 def main():
     args = parse_args()
-    world, rank, local_rank = qdist.init()
+    world, rank, local_rank = qdist.init(args.dist_backend)
+    if args.dist_backend == "gloo":
+        local_rank = 0  # rehearsal: every rank shares cuda:0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus {} needs one process per GPU: launch with "
@@ -90,9 +96,12 @@ def main():
     hw = (args.height, args.width)
     B = args.batch
     weights = synth.make_weights(42, hw)
-    model = build_flower(True, hw, "channels_last", weights=weights, device=dev, fused=args.fused)
+    tdtype = torch.float32 if args.dtype == "f32" else torch.float16
+    esize = 4 if args.dtype == "f32" else 2
+    model = build_flower(True, hw, "channels_last", weights=weights, device=dev, fused=args.fused,
+                         dtype=tdtype)
     pairs_np, gt_np = synth.make_frames(B, hw[0], hw[1], seed=1234 + rank)
-    pairs = torch.from_numpy(pairs_np).to(dev)
+    pairs = torch.from_numpy(pairs_np).to(dev, tdtype)
     gt = torch.from_numpy(gt_np).to(dev)
     shapes = [(hw[0] >> s, hw[1] >> s) for s in (5, 4, 3, 2, 1, 0)]
     gt_pyr = metrics.multiscale_ground_truth(gt, shapes)
@@ -124,6 +133,9 @@ def main():
             e = epe_local
         else:
             _, e = forward()
+        if args.dist_backend == "gloo":
+            per_rank, mean = qdist.gather_epe(e.cpu(), B)
+            return per_rank, mean
         return qdist.gather_epe(e, B)
 
     for _ in range(args.warmup):
@@ -147,7 +159,7 @@ def main():
     dom_name = "warp_cost_volume" if args.fused else "cost_volume"
     dom_key = (dom_name,) + lvl4
     _, dom_ms = ktimes[dom_key]
-    dom_bytes = cost_volume_bytes(*lvl4)
+    dom_bytes = cost_volume_bytes(*lvl4, esize)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from a separate rocprofv3 --pmc run
@@ -165,13 +177,15 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1]: full 6-level PWC-Net (qpwcnet build_flower) inference, "
-                        "batch {} per GPU, {}x{} fp32, d=4 cost volume + WarpV2".format(B, hw[0], hw[1]),
+                        "batch {} per GPU, {}x{} {}, d=4 cost volume + WarpV2".format(
+                            B, hw[0], hw[1], "fp32" if args.dtype == "f32" else "fp16"),
             "global_batch": world * B, "batch_per_gpu": B,
             "parallelism": "dp{} (pairs sharded, RCCL all-gather of the 6 per-level EPE)".format(world),
             "hipgraph": graph is not None, "fused_upflow": bool(args.fused),
+            "hip_optflow": args.dtype == "f32",
             "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",
         },
         "roofline": {

@@ -140,6 +140,11 @@ int qpwc_flow_head_param_floats(void);
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W,
                        float scale, void* stream);
 
+/* x = Mish(x + bias[c]) in place, channels-last fp32 (n_pixels, C), C % 4 == 0, bias may
+ * be NULL: the `activation='Mish'` epilogue of the reference's Conv2D / Conv2DTranspose /
+ * SeparableConv2D blocks (non_layers.py:196-210, 223-231, 390-449; mish.py:27-28). */
+int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

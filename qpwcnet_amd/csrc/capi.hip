@@ -40,6 +40,7 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      hipStream_t s);
 int flow_head_param_floats();
+int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -220,6 +221,13 @@ int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int 
     if (overlaps(out, (size_t)B * H * W * 8, z, (size_t)B * H * W * 64))
         return fail(QPWC_E_ALIAS, "out overlaps z");
     return flow_head_launch(z, params, out, B, H, W, scale, (hipStream_t)stream);
+}
+
+int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, void* stream) {
+    if (!x) return fail(QPWC_E_NULL, "null pointer argument");
+    if (n_pixels <= 0 || C <= 0 || C % 4) return fail(QPWC_E_SHAPE, "need n_pixels > 0 and C %% 4 == 0 (C=%d)", C);
+    if ((uintptr_t)x % 16 || (uintptr_t)bias % 16) return fail(QPWC_E_ALIGN, "x and bias must be 16-byte aligned");
+    return bias_mish_launch(x, bias, n_pixels, C, (hipStream_t)stream);
 }
 
 }  // extern "C"

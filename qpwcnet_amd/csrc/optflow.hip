@@ -230,6 +230,35 @@ __global__ __launch_bounds__(256, 4) void flow_head_kernel(const float* __restri
     *o = make_float2(scale * fx, scale * fy);
 }
 
+// ---------------------------------------------------------------------------
+// x = Mish(x + bias[c]) in place on a channels-last tensor: the `activation='Mish'`
+// epilogue of the reference's Conv2D / Conv2DTranspose blocks (non_layers.py:196-210,
+// 390-449).  The library convolution runs without bias; bias add and activation are
+// one bandwidth-bound pass instead of two.
+__global__ __launch_bounds__(256) void bias_mish_kernel(float* __restrict__ x,
+                                                        const float* __restrict__ bias, int64_t n4,
+                                                        int c4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        if (bias) {
+            const float4 b = reinterpret_cast<const float4*>(bias)[i % c4];
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        v.x = mishf(v.x); v.y = mishf(v.y); v.z = mishf(v.z); v.w = mishf(v.w);
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+}
+
+int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, hipStream_t s) {
+    const int64_t n4 = n_pixels * C / 4;
+    const int64_t want = (n4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(bias_mish_kernel, dim3(grid), dim3(256), 0, s, (float*)x, (const float*)bias, n4,
+                       C / 4);
+    return check_launch("bias_mish_kernel");
+}
+
 int flow_head_param_floats() { return kFhParams; }
 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,

@@ -148,14 +148,27 @@ class _Weighted(_Functor):
         return self.params[self.prefix + name]
 
 
+def _hip_act_ok(y_nchw, data_format):
+    """The fused bias+Mish kernel applies to fp32 GPU tensors that are physically NHWC."""
+    return (data_format == CHANNELS_LAST and y_nchw.is_cuda and y_nchw.dtype == torch.float32 and
+            y_nchw.shape[1] % 4 == 0 and y_nchw.permute(0, 2, 3, 1).is_contiguous())
+
+
+def _bias_mish(y_nchw, bias, data_format):
+    """Mish(y + bias) for a bias-free library convolution output; HIP epilogue when possible."""
+    if _hip_act_ok(y_nchw, data_format):
+        ops.bias_mish_(y_nchw.permute(0, 2, 3, 1), bias)
+        return y_nchw
+    return F.mish(y_nchw + bias.view(1, -1, 1, 1))
+
+
 class UpConv(_Weighted):
     """qpwcnet/core/non_layers.py:196-210: Conv2DTranspose(k=4, s=2, 'same') + Mish
     == ConvTranspose2d(k=4, s=2, padding=1)."""
 
     def __call__(self, x):
-        y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), self.p("conv_up.bias"),
-                               stride=2, padding=1)
-        return self._fmt(F.mish(y))
+        y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), None, stride=2, padding=1)
+        return self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.data_format))
 
 
 class DownConv(_Weighted):
@@ -164,9 +177,9 @@ class DownConv(_Weighted):
 
     def __call__(self, x):
         y = self._nchw(x)
-        y = F.mish(conv2d_same(y, self.p("conv_a.weight"), self.p("conv_a.bias"), 2))
-        y = F.mish(conv2d_same(y, self.p("conv_aa.weight"), self.p("conv_aa.bias"), 1))
-        y = F.mish(conv2d_same(y, self.p("conv_b.weight"), self.p("conv_b.bias"), 1))
+        for name, stride in (("conv_a", 2), ("conv_aa", 1), ("conv_b", 1)):
+            y = conv2d_same(y, self.p(name + ".weight"), None, stride)
+            y = _bias_mish(y, self.p(name + ".bias"), self.data_format)
         return self._fmt(y)
 
 

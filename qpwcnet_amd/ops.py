@@ -314,3 +314,21 @@ def flow_head(z, params, scale):
                                   float(scale), _stream(z))
     _hip.check(rc)
     return out
+
+
+def bias_mish_(x_nhwc, bias=None):
+    """In place x = Mish(x + bias) on a dense channels-last fp32 tensor (..., C), C % 4 == 0 --
+    the `activation='Mish'` epilogue of the reference's conv blocks (non_layers.py:196-210,
+    390-449).  Returns x."""
+    _check_tensor("x", x_nhwc)
+    if x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous():
+        raise ValueError("bias_mish_ needs a dense fp32 channels-last tensor")
+    C = x_nhwc.shape[-1]
+    if bias is not None and (bias.numel() != C or bias.dtype != torch.float32 or not bias.is_cuda):
+        raise ValueError("bias must be a fp32 device vector of {} elements".format(C))
+    n = x_nhwc.numel() // C
+    with torch.cuda.device(x_nhwc.device), _timed("bias_mish", tuple(x_nhwc.shape)):
+        rc = _hip.lib().qpwc_bias_mish_fwd(x_nhwc.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                            n, C, _stream(x_nhwc))
+    _hip.check(rc)
+    return x_nhwc

@@ -97,3 +97,18 @@ def test_full_network_both_optflow_paths(hip_optflow):
     for lvl, (x, y) in enumerate(zip(flows, ref)):
         e = float(torch_ref.epe_error(x.cpu(), y))
         assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
+
+
+def test_bias_mish_inplace():
+    """`activation='Mish'` epilogue (qpwcnet/core/mish.py:27-28) vs the oracle's definition."""
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy((rng.standard_normal((3, 17, 19, 32)) * 6).astype(np.float32))
+    x[0, 0, 0, :4] = torch.tensor([25.0, -30.0, 0.0, 88.0])     # softplus threshold / tails
+    b = torch.from_numpy(rng.standard_normal(32).astype(np.float32))
+    ref = torch_ref.mish(x.double() + b.double()).float()
+    out = ops.bias_mish_(x.to(DEV).clone(), b.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, rtol=2e-6, atol=2e-6)
+    out2 = ops.bias_mish_(x.to(DEV).clone()).cpu()
+    torch.testing.assert_close(out2, torch_ref.mish(x.double()).float(), rtol=2e-6, atol=2e-6)
+    with pytest.raises(ValueError):
+        ops.bias_mish_(torch.zeros(2, 2, 2, 6, device=DEV))

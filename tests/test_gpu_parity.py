@@ -296,3 +296,20 @@ def test_full_network_channels_first():
     ref = net_ref.RefNet(weights)(pairs)
     for a, b in zip(flows, ref):
         assert float(torch_ref.epe_error(a.permute(0, 2, 3, 1).cpu(), b)) < TOL
+
+
+def test_full_network_fp16_config5():
+    """BASELINE configs[4]: fp16 storage/convs, fp32 accumulation in the hot path.  The
+    reference has no fp16 path; the bound is build-defined: per-level EPE vs the fp32 oracle
+    below 5 % of the flow magnitude at that level."""
+    hw = (64, 128)
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(2, hw[0], hw[1], seed=1234)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV, dtype=torch.float16)
+    flows = model.predict(pairs)
+    ref = net_ref.RefNet(weights)(pairs)
+    for lvl, (a, b) in enumerate(zip(flows, ref)):
+        assert a.dtype == torch.float16
+        e = float(torch_ref.epe_error(a.float().cpu(), b))
+        mag = float(torch.linalg.vector_norm(b, dim=-1).mean())
+        assert e < 0.05 * max(mag, 0.1), "level {}: EPE {:.3e} vs |flow| {:.3e}".format(lvl, e, mag)
