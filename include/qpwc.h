@@ -145,6 +145,11 @@ int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int 
  * SeparableConv2D blocks (non_layers.py:196-210, 223-231, 390-449; mish.py:27-28). */
 int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, void* stream);
 
+/* Upsample(scale) of a flow field (non_layers.py:183-193; pwcnet.py:55,60):
+ * out (B,2h,2w,2) = scale * bilinear x2 upsampling (half-pixel centres, edge clamp) of
+ * in (B,h,w,2), fp32 channels-last. */
+int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ SYMBOLS = (
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_bias_mish_fwd",
+    "qpwc_upsample2x_flow_fwd",
 )
 
 _lib = None
@@ -86,6 +87,8 @@ def lib():
     L.qpwc_flow_head_fwd.restype = ci
     L.qpwc_bias_mish_fwd.argtypes = [vp, vp, i64, ci, vp]
     L.qpwc_bias_mish_fwd.restype = ci
+    L.qpwc_upsample2x_flow_fwd.argtypes = [vp, vp, ci, ci, ci, cf, vp]
+    L.qpwc_upsample2x_flow_fwd.restype = ci
     _lib = L
     return L
 

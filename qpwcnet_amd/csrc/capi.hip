@@ -40,6 +40,7 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      hipStream_t s);
 int flow_head_param_floats();
+int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
@@ -228,6 +229,15 @@ int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, void*
     if (n_pixels <= 0 || C <= 0 || C % 4) return fail(QPWC_E_SHAPE, "need n_pixels > 0 and C %% 4 == 0 (C=%d)", C);
     if ((uintptr_t)x % 16 || (uintptr_t)bias % 16) return fail(QPWC_E_ALIGN, "x and bias must be 16-byte aligned");
     return bias_mish_launch(x, bias, n_pixels, C, (hipStream_t)stream);
+}
+
+int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, void* stream) {
+    if (!in || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (B <= 0 || h <= 0 || w <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d h=%d w=%d", B, h, w);
+    if ((uintptr_t)in % 8 || (uintptr_t)out % 8) return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte aligned");
+    if (overlaps(out, (size_t)B * 4 * h * w * 8, in, (size_t)B * h * w * 8))
+        return fail(QPWC_E_ALIAS, "out overlaps in");
+    return upsample2x_flow_launch(in, out, B, h, w, scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

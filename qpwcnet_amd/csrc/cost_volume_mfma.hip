@@ -406,6 +406,15 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     }
 }
 
+// QPWC_CV_LDS=0 keeps every shape on the per-wave split-K kernel (A/B measurements only).
+static int lds_mode() {
+    static const int v = [] {
+        const char* e = getenv("QPWC_CV_LDS");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+
 static int launch_lds(const float* prv, const float* nxt, float* out, int B, int H, int W, int C,
                       int64_t ops, float slope, hipStream_t s) {
     const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
@@ -419,15 +428,6 @@ static int launch_lds(const float* prv, const float* nxt, float* out, int B, int
     hipLaunchKernelGGL(cost_volume_mfma_lds_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
                        H, W, C, regs_x, regs_y, (int)ops, slope, inv_c);
     return check_launch("cost_volume_mfma_lds_kernel");
-}
-
-// QPWC_CV_LDS=0 disables the workgroup-shared variant (A/B measurements only).
-static bool use_lds() {
-    static const bool v = [] {
-        const char* e = getenv("QPWC_CV_LDS");
-        return !(e && e[0] == '0');
-    }();
-    return v;
 }
 
 template <typename T, int CPL, int KS>
@@ -474,7 +474,7 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
         return 1;
     if (dtype == QPWC_F32) {
         // many tiles: share the staged neighbourhood across a workgroup
-        if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 1024 && use_lds())
+        if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 1024 && lds_mode() != 0)
             return launch_lds((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C, ops, slope, s);
         if (C % 32 == 0)
             return dispatch_mfma<float, 8>((const float*)prv, (const float*)nxt, (float*)out, B, H, W,

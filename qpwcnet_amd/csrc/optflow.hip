@@ -259,6 +259,41 @@ int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, hipStre
     return check_launch("bias_mish_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// Upsample(scale): scale * UpSampling2D(2, 'bilinear') of a flow field (B,h,w,2)
+// (non_layers.py:183-193; half-pixel centres, edge-clamped: src = max(0, (dst+.5)/2 - .5)).
+__global__ __launch_bounds__(256) void upsample2x_flow_kernel(const float2* __restrict__ in,
+                                                              float2* __restrict__ out, int B, int h,
+                                                              int w, float scale) {
+    const int H = 2 * h, W = 2 * w;
+    const int64_t total = (int64_t)B * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = idx % W;
+        const int y = (idx / W) % H;
+        const int b = idx / ((int64_t)W * H);
+        const float sy = fmaxf(0.0f, (y + 0.5f) * 0.5f - 0.5f), sx = fmaxf(0.0f, (x + 0.5f) * 0.5f - 0.5f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+        const float ly = sy - y0, lx = sx - x0;
+        const float2* p = in + (int64_t)b * h * w;
+        const float2 v00 = p[y0 * w + x0], v01 = p[y0 * w + x1], v10 = p[y1 * w + x0], v11 = p[y1 * w + x1];
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+        float2 r;
+        r.x = scale * (w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x);
+        r.y = scale * (w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y);
+        out[idx] = r;
+    }
+}
+
+int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, hipStream_t s) {
+    const int64_t total = (int64_t)B * 4 * h * w;
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(upsample2x_flow_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s,
+                       (const float2*)in, (float2*)out, B, h, w, scale);
+    return check_launch("upsample2x_flow_kernel");
+}
+
 int flow_head_param_floats() { return kFhParams; }
 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,

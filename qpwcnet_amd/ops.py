@@ -332,3 +332,19 @@ def bias_mish_(x_nhwc, bias=None):
                                             n, C, _stream(x_nhwc))
     _hip.check(rc)
     return x_nhwc
+
+
+def upsample2x_flow(flo, scale=1.0):
+    """scale * bilinear x2 upsampling of a channels-last fp32 flow (B,h,w,2) -- the reference's
+    Upsample functor (non_layers.py:183-193) as used on flows (pwcnet.py:55,60)."""
+    _check_tensor("flo", flo)
+    if flo.dtype != torch.float32 or flo.shape[3] != 2:
+        raise ValueError("upsample2x_flow takes a fp32 (B,h,w,2) tensor")
+    f = flo.contiguous()
+    B, h, w, _ = f.shape
+    out = torch.empty((B, 2 * h, 2 * w, 2), dtype=torch.float32, device=f.device)
+    with torch.cuda.device(f.device), _timed("upsample2x_flow", (B, h, w, 2)):
+        rc = _hip.lib().qpwc_upsample2x_flow_fwd(f.data_ptr(), out.data_ptr(), B, h, w, float(scale),
+                                                  _stream(f))
+    _hip.check(rc)
+    return out

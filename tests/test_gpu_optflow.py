@@ -112,3 +112,15 @@ def test_bias_mish_inplace():
     torch.testing.assert_close(out2, torch_ref.mish(x.double()).float(), rtol=2e-6, atol=2e-6)
     with pytest.raises(ValueError):
         ops.bias_mish_(torch.zeros(2, 2, 2, 6, device=DEV))
+
+
+@pytest.mark.parametrize("hw", [(8, 16), (5, 7), (128, 256)])
+def test_upsample2x_flow(hw):
+    """Upsample functor (non_layers.py:183-193) vs the oracle's F.interpolate restatement."""
+    rng = np.random.default_rng(hw[0])
+    f = torch.from_numpy(rng.standard_normal((2, hw[0], hw[1], 2)).astype(np.float32))
+    ref = net_ref.RefNet.upsample(f, 2.0)
+    out = ops.upsample2x_flow(f.to(DEV), 2.0).cpu()
+    torch.testing.assert_close(out, ref, rtol=0, atol=2e-6)
+    out2 = non_layers.Upsample(scale=2.0, data_format="channels_last")(f.to(DEV)).cpu()
+    torch.testing.assert_close(out2, ref, rtol=0, atol=2e-6)
