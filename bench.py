@@ -185,7 +185,7 @@ def main():
             "global_batch": world * B, "batch_per_gpu": B,
             "parallelism": "dp{} (pairs sharded, RCCL all-gather of the 6 per-level EPE)".format(world),
             "hipgraph": graph is not None, "fused_upflow": bool(args.fused),
-            "hip_optflow": args.dtype == "f32",
+            "hip_optflow": True,
             "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",
         },
         "roofline": {

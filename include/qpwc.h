@@ -124,11 +124,12 @@ int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* w
  * in0 = (mish_on_load ? Mish(in) : in) inside the image and 0 outside.
  * `in` is the channel-wise concatenation of n_src (1..3) channels-last fp32 sources:
  * source i contributes src_channels[i] channels read at src[i] + pixel*src_pixel_stride[i]
- * (elements) -- Flow/UpFlow's concat([cost, prv, flo]) (non_layers.py:336-338,381-385) is
+ * (elements; all sources and `out` share the storage `dtype`, weights/params stay fp32,
+ * arithmetic is fp32) -- Flow/UpFlow's concat([cost, prv, flo]) (non_layers.py:336-338,381-385) is
  * never materialised.  weight: (C,3,3) fp32, C = sum(src_channels); out: (B,H,W,C) dense. */
 int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
                        const int64_t* src_pixel_stride, int n_src, int mish_on_load,
-                       const void* weight, void* out, int B, int H, int W, void* stream);
+                       const void* weight, void* out, int B, int H, int W, int dtype, void* stream);
 
 /* Tail of OptFlow.__call__ (non_layers.py:238-254, 268-273) on the 16-channel
  * pre-activation output z (B,H,W,16) of the last SeparableConv's pointwise conv:
@@ -138,17 +139,18 @@ int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
  * with bn_scale = gamma/sqrt(var+eps), bn_shift = beta - mean*bn_scale.  out: (B,H,W,2). */
 int qpwc_flow_head_param_floats(void);
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W,
-                       float scale, void* stream);
+                       float scale, int dtype, void* stream);
 
 /* x = Mish(x + bias[c]) in place, channels-last fp32 (n_pixels, C), C % 4 == 0, bias may
  * be NULL: the `activation='Mish'` epilogue of the reference's Conv2D / Conv2DTranspose /
  * SeparableConv2D blocks (non_layers.py:196-210, 223-231, 390-449; mish.py:27-28). */
-int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, void* stream);
+int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int dtype, void* stream);
 
 /* Upsample(scale) of a flow field (non_layers.py:183-193; pwcnet.py:55,60):
  * out (B,2h,2w,2) = scale * bilinear x2 upsampling (half-pixel centres, edge clamp) of
  * in (B,h,w,2), fp32 channels-last. */
-int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, void* stream);
+int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, int dtype,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,15 +79,15 @@ def lib():
     L.qpwc_epe_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.qpwc_epe_fwd.restype = ci
     L.qpwc_dwconv3x3_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(i64),
-                                     ci, ci, vp, vp, ci, ci, ci, vp]
+                                     ci, ci, vp, vp, ci, ci, ci, ci, vp]
     L.qpwc_dwconv3x3_fwd.restype = ci
     L.qpwc_flow_head_param_floats.argtypes = []
     L.qpwc_flow_head_param_floats.restype = ci
-    L.qpwc_flow_head_fwd.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp]
+    L.qpwc_flow_head_fwd.argtypes = [vp, vp, vp, ci, ci, ci, cf, ci, vp]
     L.qpwc_flow_head_fwd.restype = ci
-    L.qpwc_bias_mish_fwd.argtypes = [vp, vp, i64, ci, vp]
+    L.qpwc_bias_mish_fwd.argtypes = [vp, vp, i64, ci, ci, vp]
     L.qpwc_bias_mish_fwd.restype = ci
-    L.qpwc_upsample2x_flow_fwd.argtypes = [vp, vp, ci, ci, ci, cf, vp]
+    L.qpwc_upsample2x_flow_fwd.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp]
     L.qpwc_upsample2x_flow_fwd.restype = ci
     _lib = L
     return L

@@ -36,12 +36,14 @@ int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int
                int layout, hipStream_t s);
 
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
-                     int act, const void* weight, void* out, int B, int H, int W, hipStream_t s);
-int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
+                     int act, const void* weight, void* out, int B, int H, int W, int dtype,
                      hipStream_t s);
+int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
+                     int dtype, hipStream_t s);
 int flow_head_param_floats();
-int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, hipStream_t s);
-int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, hipStream_t s);
+int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, int dtype,
+                           hipStream_t s);
+int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -187,9 +189,11 @@ int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* w
 
 int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
                        const int64_t* src_pixel_stride, int n_src, int mish_on_load,
-                       const void* weight, void* out, int B, int H, int W, void* stream) {
+                       const void* weight, void* out, int B, int H, int W, int dtype, void* stream) {
     if (!src || !src_channels || !src_pixel_stride || !weight || !out)
         return fail(QPWC_E_NULL, "null pointer argument");
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
+    const size_t es = esize(dtype);
     if (n_src < 1 || n_src > 3) return fail(QPWC_E_SHAPE, "n_src %d outside [1,3]", n_src);
     if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
     int64_t C = 0;
@@ -198,46 +202,53 @@ int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
         if (src_channels[i] <= 0 || src_pixel_stride[i] < src_channels[i])
             return fail(QPWC_E_STRIDE, "source %d: %d channels at pixel stride %lld", i,
                         src_channels[i], (long long)src_pixel_stride[i]);
-        if ((uintptr_t)src[i] % 4) return fail(QPWC_E_ALIGN, "source %d not 4-byte aligned", i);
+        if ((uintptr_t)src[i] % es) return fail(QPWC_E_ALIGN, "source %d not element aligned", i);
         C += src_channels[i];
     }
-    if ((uintptr_t)out % 4 || (uintptr_t)weight % 4) return fail(QPWC_E_ALIGN, "pointer not 4-byte aligned");
-    const size_t n_out = (size_t)B * H * W * C * 4;
+    if ((uintptr_t)out % es || (uintptr_t)weight % 4) return fail(QPWC_E_ALIGN, "pointer not element aligned");
+    const size_t n_out = (size_t)B * H * W * C * es;
     for (int i = 0; i < n_src; ++i)
-        if (overlaps(out, n_out, src[i], (size_t)B * H * W * src_pixel_stride[i] * 4))
+        if (overlaps(out, n_out, src[i], (size_t)B * H * W * src_pixel_stride[i] * es))
             return fail(QPWC_E_ALIAS, "out overlaps source %d", i);
     if ((int64_t)W * C > INT32_MAX) return fail(QPWC_E_SHAPE, "row too long");
     return dwconv3x3_launch(src, src_channels, src_pixel_stride, n_src, mish_on_load, weight, out, B,
-                            H, W, (hipStream_t)stream);
+                            H, W, dtype, (hipStream_t)stream);
 }
 
 int qpwc_flow_head_param_floats(void) { return flow_head_param_floats(); }
 
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W, float scale,
-                       void* stream) {
+                       int dtype, void* stream) {
     if (!z || !params || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
+    const size_t es = esize(dtype);
     if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
-    if ((uintptr_t)z % 16 || (uintptr_t)out % 8 || (uintptr_t)params % 4)
-        return fail(QPWC_E_ALIGN, "z must be 16-byte, out 8-byte aligned");
-    if (overlaps(out, (size_t)B * H * W * 8, z, (size_t)B * H * W * 64))
+    if ((uintptr_t)z % (4 * es) || (uintptr_t)out % (2 * es) || (uintptr_t)params % 4)
+        return fail(QPWC_E_ALIGN, "z must be aligned to 4 elements, out to 2");
+    if (overlaps(out, (size_t)B * H * W * 2 * es, z, (size_t)B * H * W * 16 * es))
         return fail(QPWC_E_ALIAS, "out overlaps z");
-    return flow_head_launch(z, params, out, B, H, W, scale, (hipStream_t)stream);
+    return flow_head_launch(z, params, out, B, H, W, scale, dtype, (hipStream_t)stream);
 }
 
-int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, void* stream) {
+int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int dtype, void* stream) {
     if (!x) return fail(QPWC_E_NULL, "null pointer argument");
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
     if (n_pixels <= 0 || C <= 0 || C % 4) return fail(QPWC_E_SHAPE, "need n_pixels > 0 and C %% 4 == 0 (C=%d)", C);
-    if ((uintptr_t)x % 16 || (uintptr_t)bias % 16) return fail(QPWC_E_ALIGN, "x and bias must be 16-byte aligned");
-    return bias_mish_launch(x, bias, n_pixels, C, (hipStream_t)stream);
+    if ((uintptr_t)x % (4 * esize(dtype)) || (uintptr_t)bias % 16)
+        return fail(QPWC_E_ALIGN, "x must be aligned to 4 elements, bias to 16 bytes");
+    return bias_mish_launch(x, bias, n_pixels, C, dtype, (hipStream_t)stream);
 }
 
-int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, void* stream) {
+int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, int dtype,
+                             void* stream) {
     if (!in || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
+    const size_t es = esize(dtype);
     if (B <= 0 || h <= 0 || w <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d h=%d w=%d", B, h, w);
-    if ((uintptr_t)in % 8 || (uintptr_t)out % 8) return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte aligned");
-    if (overlaps(out, (size_t)B * 4 * h * w * 8, in, (size_t)B * h * w * 8))
+    if ((uintptr_t)in % es || (uintptr_t)out % es) return fail(QPWC_E_ALIGN, "flow pointers must be element aligned");
+    if (overlaps(out, (size_t)B * 4 * h * w * 2 * es, in, (size_t)B * h * w * 2 * es))
         return fail(QPWC_E_ALIAS, "out overlaps in");
-    return upsample2x_flow_launch(in, out, B, h, w, scale, (hipStream_t)stream);
+    return upsample2x_flow_launch(in, out, B, h, w, scale, dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -406,6 +406,134 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// fp16 storage (BASELINE configs[4]): same workgroup-shared scheme on the fp16 matrix
+// cores, v_mfma_f32_16x16x32_f16 (fp32 accumulate): one instruction per block per
+// 32-channel step instead of eight, so the kernel is purely bandwidth-bound.
+// LDS image: block = 16 px x 64 B; 16-byte chunk c (8 channels) of pixel n at chunk
+// c ^ ((n >> 2) & 2): conflict-free staging writes and ds_read_b128 operand reads.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kRegStageBytesH = kRegBlocks * 1024;
+constexpr int kRegLdsBytesH = kRegStageBytesH > 4 * kFrameFloats * 4 ? kRegStageBytesH : 4 * kFrameFloats * 4;
+
+__global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
+    const __half* __restrict__ prv, const __half* __restrict__ nxt, __half* __restrict__ out, int H,
+    int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c) {
+    __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytesH];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int region = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int rx = region % regs_x, ry = (region / regs_x) % regs_y, b = region / (regs_x * regs_y);
+    const int X0 = rx * 8, Y0 = ry * 8;
+
+    const int img_bytes = H * W * C * 2;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__half*>(prv) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__half*>(nxt) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+
+    // staging map: piece idx = it*256 + tid -> block 4*it + wave, pixel lane>>2, chunk lane&3
+    const int sn = lane >> 2, sc = lane & 3;
+    const int spy = sn >> 2, spx = sn & 3;
+    const int lds_w = wave * 1024 + sn * 64 + ((sc ^ ((sn >> 2) & 2)) << 4);  // + it*4096
+    unsigned goff[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int blk = 4 * it + wave;  // wave-uniform
+        int y, x;
+        if (blk < 16) {
+            y = Y0 - 4 + 4 * (blk >> 2) + spy;
+            x = X0 - 4 + 4 * (blk & 3) + spx;
+        } else {
+            y = Y0 + 4 * ((blk - 16) >> 1) + spy;
+            x = X0 + 4 * ((blk - 16) & 1) + spx;
+        }
+        goff[it] = (x >= 0 && x < W) ? (unsigned)((y * W + x) * C * 2 + sc * 16) : kOob;
+    }
+
+    const int n = lane & 15, g = lane >> 4;
+    const int ti = wave >> 1, tj = wave & 1;
+    const int coff = n * 64 + ((g ^ ((n >> 2) & 2)) << 4);
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = C / 32;
+    for (int s = 0; s < nsteps; ++s) {
+        const int soff = s * 64;
+        u32x4 st[5];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
+        st[4] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[4], soff, 0);
+        if (s > 0) __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 5; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = st[it];
+        __syncthreads();
+        const f16x8 pv = *reinterpret_cast<const f16x8*>(smem + (16 + wave) * 1024 + coff);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f16x8 nv = *reinterpret_cast<const f16x8*>(smem + ((ti + i) * 4 + tj + j) * 1024 + coff);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nv, pv, acc[i][j], 0, 0, 0);
+            }
+    }
+    __syncthreads();
+
+    float* fr = reinterpret_cast<float*>(smem) + wave * kFrameFloats;
+    {
+        float* dst = fr + n * kFramePS + g * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(dst + 48 * i + 4 * j) = acc[i][j];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
+    if (x0 >= W || y0 >= H) return;
+    const bool use_mul = inv_c > 0.f;
+    const float scale = use_mul ? inv_c : (float)C;
+    __half* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
+    const int row_stride = W * out_pix_stride;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int e = lane + 64 * s;
+        const int epx = e / 81, k = e - 81 * epx;
+        const int ky = k / 9, kx = k - 9 * ky;
+        const bool e_ok = e < 324 && x0 + epx < W;
+        const int foff = epx * kFramePS + epx + ky * 12 + kx;
+        const unsigned go = (unsigned)(epx * out_pix_stride + k);
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            if (e_ok && y0 + row < H) {
+                float v = fr[foff + row * kRowStep];
+                v = use_mul ? v * scale : v / scale;
+                ob[(int64_t)row * row_stride + go] = __float2half_rn(lrelu(v, slope));
+            }
+        }
+    }
+}
+
+static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int B, int H, int W, int C,
+                          int64_t ops, float slope, hipStream_t s) {
+    const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
+    const int64_t nblk = (int64_t)regs_x * regs_y * B;
+    if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * 2 >= 0x7fffffff ||
+        (int64_t)H * W * ops > INT32_MAX) {
+        set_error("image too large for 32-bit tile indexing");
+        return QPWC_E_SHAPE;
+    }
+    const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
+    hipLaunchKernelGGL(cost_volume_mfma_lds_f16_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
+                       out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c);
+    return check_launch("cost_volume_mfma_lds_f16_kernel");
+}
+
 // QPWC_CV_LDS=0 keeps every shape on the per-wave split-K kernel (A/B measurements only).
 static int lds_mode() {
     static const int v = [] {
@@ -482,6 +610,8 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
         return dispatch_mfma<float, 4>((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C,
                                        ops, slope, s);
     }
+    if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 256 && lds_mode() != 0)
+        return launch_lds_f16((const __half*)prv, (const __half*)nxt, (__half*)out, B, H, W, C, ops, slope, s);
     if (C % 32 == 0)
         return dispatch_mfma<__half, 8>((const __half*)prv, (const __half*)nxt, (__half*)out, B, H,
                                         W, C, ops, slope, s);

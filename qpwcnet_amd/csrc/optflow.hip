@@ -33,7 +33,7 @@ __device__ __forceinline__ float mishf(float x) {
 }
 
 struct DwSrc {
-    const float* ptr[3];
+    const void* ptr[3];
     int ch[3];          // channels taken from each source (0 = unused)
     int64_t stride[3];  // floats per pixel of each source
 };
@@ -45,9 +45,9 @@ constexpr int kDwPx = 4;    // consecutive pixels per thread
 // Mish once to each (1.5 evaluations per output instead of 3 for one pixel per thread),
 // and keeps a rolling 3-row window; the raw values of the next row are requested one
 // iteration ahead so that the loop does not wait on a load it has just issued.
-template <bool ACT>
+template <typename T, bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* __restrict__ weight,
-                                                        float* __restrict__ out, int H, int W, int C,
+                                                        T* __restrict__ out, int H, int W, int C,
                                                         int strips, int wq) {
     const int64_t rowthreads = (int64_t)wq * C;  // (x-quad, channel) pairs of one row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,15 +58,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
     const int y0 = strip * kDwRows;
 
     // which source holds channel c
-    const float* p;
+    const T* p;
     int64_t ps;
     int cc;
     if (c < src.ch[0]) {
-        p = src.ptr[0]; ps = src.stride[0]; cc = c;
+        p = (const T*)src.ptr[0]; ps = src.stride[0]; cc = c;
     } else if (c < src.ch[0] + src.ch[1]) {
-        p = src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
+        p = (const T*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
     } else {
-        p = src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
+        p = (const T*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
     }
     p += (int64_t)b * H * W * ps + cc;
 
@@ -80,9 +80,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
 
     auto load_raw = [&](int y, float (&r)[kDwPx + 2]) {
         const bool row_ok = y >= 0 && y < H;
-        const float* q = p + ((int64_t)y * W + (x0 - 1)) * ps;
+        const T* q = p + ((int64_t)y * W + (x0 - 1)) * ps;
 #pragma unroll
-        for (int j = 0; j < kDwPx + 2; ++j) r[j] = (row_ok && col_ok[j]) ? q[(int64_t)j * ps] : 0.0f;
+        for (int j = 0; j < kDwPx + 2; ++j) r[j] = (row_ok && col_ok[j]) ? ld(q + (int64_t)j * ps) : 0.0f;
     };
     auto activate = [&](int y, float (&r)[kDwPx + 2]) {
         if (!ACT) return;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
     load_raw(y0 + 1, ahead);
     activate(y0 - 1, r0);
     activate(y0, r1);
-    float* o = out + ((int64_t)(b * H + y0) * W + x0) * C + c;
+    T* o = out + ((int64_t)(b * H + y0) * W + x0) * C + c;
     const int64_t rowlen = (int64_t)W * C;
     const int yend = y0 + kDwRows < H ? y0 + kDwRows : H;
     for (int y = y0; y < yend; ++y) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
             a = fmaf(w[6], r2[i], a);
             a = fmaf(w[7], r2[i + 1], a);
             a = fmaf(w[8], r2[i + 2], a);
-            if (x0 + i < W) o[(int64_t)i * C] = a;
+            if (x0 + i < W) st(o + (int64_t)i * C, a);
         }
         o += rowlen;
 #pragma unroll
@@ -127,12 +127,24 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
     }
 }
 
+template <typename T>
+static void dwconv_dispatch(const DwSrc& d, int act, const void* weight, void* out, int H, int W, int C,
+                            int strips, int wq, dim3 grid, hipStream_t s) {
+    if (act)
+        hipLaunchKernelGGL((dwconv3x3_kernel<T, true>), grid, dim3(256), 0, s, d, (const float*)weight,
+                           (T*)out, H, W, C, strips, wq);
+    else
+        hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), grid, dim3(256), 0, s, d, (const float*)weight,
+                           (T*)out, H, W, C, strips, wq);
+}
+
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
-                     int act, const void* weight, void* out, int B, int H, int W, hipStream_t s) {
+                     int act, const void* weight, void* out, int B, int H, int W, int dtype,
+                     hipStream_t s) {
     DwSrc d;
     int C = 0;
     for (int i = 0; i < 3; ++i) {
-        d.ptr[i] = i < n_src ? (const float*)srcs[i] : nullptr;
+        d.ptr[i] = i < n_src ? srcs[i] : nullptr;
         d.ch[i] = i < n_src ? chans[i] : 0;
         d.stride[i] = i < n_src ? strides[i] : 0;
         C += d.ch[i];
@@ -141,12 +153,10 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
     const int wq = (W + kDwPx - 1) / kDwPx;
     const int64_t rowthreads = (int64_t)wq * C;
     const dim3 grid((unsigned)((rowthreads + 255) / 256), (unsigned)(strips * B));
-    if (act)
-        hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, dim3(256), 0, s, d, (const float*)weight,
-                           (float*)out, H, W, C, strips, wq);
+    if (dtype == QPWC_F32)
+        dwconv_dispatch<float>(d, act, weight, out, H, W, C, strips, wq, grid, s);
     else
-        hipLaunchKernelGGL(dwconv3x3_kernel<false>, grid, dim3(256), 0, s, d, (const float*)weight,
-                           (float*)out, H, W, C, strips, wq);
+        dwconv_dispatch<__half>(d, act, weight, out, H, W, C, strips, wq, grid, s);
     return check_launch("dwconv3x3_kernel");
 }
 
@@ -157,10 +167,11 @@ constexpr int kFhC = 16;
 constexpr int kFhTile = 16;
 constexpr int kFhParams = 592;  // == qpwc_flow_head_param_floats()
 
-__global__ __launch_bounds__(256, 4) void flow_head_kernel(const float* __restrict__ z,
-                                                        const float* __restrict__ params,
-                                                        float* __restrict__ out, int H, int W,
-                                                        int tiles_x, int tiles_y, float scale) {
+template <typename T>
+__global__ __launch_bounds__(256, 4) void flow_head_kernel(const T* __restrict__ z,
+                                                           const float* __restrict__ params,
+                                                           T* __restrict__ out, int H, int W,
+                                                           int tiles_x, int tiles_y, float scale) {
     constexpr int TW = kFhTile + 2;
     __shared__ __attribute__((aligned(16))) float hs[TW * TW * kFhC];  // 18*18*16*4 = 20.7 KB
     const int tid = threadIdx.x;
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256, 4) void flow_head_kernel(const float* __restri
     const float* bs = params + 272;
     const float* bt = params + 288;
     const float* wf = params + 304;
-    const float* zb = z + (int64_t)b * H * W * kFhC;
+    const T* zb = z + (int64_t)b * H * W * kFhC;
 
     // stage h3 = BN(mish(W1 mish(z) + b1)) for the tile + 1 halo; zero outside the image
     for (int p = tid; p < TW * TW; p += 256) {
@@ -182,11 +193,11 @@ __global__ __launch_bounds__(256, 4) void flow_head_kernel(const float* __restri
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
         float h[kFhC];
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float4* q = reinterpret_cast<const float4*>(zb + ((int64_t)gy * W + gx) * kFhC);
+            const T* q = zb + ((int64_t)gy * W + gx) * kFhC;
             float a[kFhC];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 v = q[i];
+                const float4 v = ld4(q + 4 * i);
                 a[4 * i] = mishf(v.x); a[4 * i + 1] = mishf(v.y);
                 a[4 * i + 2] = mishf(v.z); a[4 * i + 3] = mishf(v.w);
             }
@@ -226,8 +237,9 @@ __global__ __launch_bounds__(256, 4) void flow_head_kernel(const float* __restri
                 fx = fmaf(v.w, wk[(4 * i + 3) * 2], fx); fy = fmaf(v.w, wk[(4 * i + 3) * 2 + 1], fy);
             }
         }
-    float2* o = reinterpret_cast<float2*>(out + ((int64_t)(b * H + gy) * W + gx) * 2);
-    *o = make_float2(scale * fx, scale * fy);
+    T* o = out + ((int64_t)(b * H + gy) * W + gx) * 2;
+    st(o, scale * fx);
+    st(o + 1, scale * fy);
 }
 
 // ---------------------------------------------------------------------------
@@ -235,35 +247,41 @@ __global__ __launch_bounds__(256, 4) void flow_head_kernel(const float* __restri
 // epilogue of the reference's Conv2D / Conv2DTranspose blocks (non_layers.py:196-210,
 // 390-449).  The library convolution runs without bias; bias add and activation are
 // one bandwidth-bound pass instead of two.
-__global__ __launch_bounds__(256) void bias_mish_kernel(float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void bias_mish_kernel(T* __restrict__ x,
                                                         const float* __restrict__ bias, int64_t n4,
                                                         int c4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        float4 v = reinterpret_cast<float4*>(x)[i];
+        float4 v = ld4(x + 4 * i);
         if (bias) {
             const float4 b = reinterpret_cast<const float4*>(bias)[i % c4];
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
         v.x = mishf(v.x); v.y = mishf(v.y); v.z = mishf(v.z); v.w = mishf(v.w);
-        reinterpret_cast<float4*>(x)[i] = v;
+        st4(x + 4 * i, v);
     }
 }
 
-int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, hipStream_t s) {
+int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s) {
     const int64_t n4 = n_pixels * C / 4;
     const int64_t want = (n4 + 255) / 256;
     const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
-    hipLaunchKernelGGL(bias_mish_kernel, dim3(grid), dim3(256), 0, s, (float*)x, (const float*)bias, n4,
-                       C / 4);
+    if (dtype == QPWC_F32)
+        hipLaunchKernelGGL(bias_mish_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x,
+                           (const float*)bias, n4, C / 4);
+    else
+        hipLaunchKernelGGL(bias_mish_kernel<__half>, dim3(grid), dim3(256), 0, s, (__half*)x,
+                           (const float*)bias, n4, C / 4);
     return check_launch("bias_mish_kernel");
 }
 
 // ---------------------------------------------------------------------------
 // Upsample(scale): scale * UpSampling2D(2, 'bilinear') of a flow field (B,h,w,2)
 // (non_layers.py:183-193; half-pixel centres, edge-clamped: src = max(0, (dst+.5)/2 - .5)).
-__global__ __launch_bounds__(256) void upsample2x_flow_kernel(const float2* __restrict__ in,
-                                                              float2* __restrict__ out, int B, int h,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restrict__ in,
+                                                              T* __restrict__ out, int B, int h,
                                                               int w, float scale) {
     const int H = 2 * h, W = 2 * w;
     const int64_t total = (int64_t)B * H * W;
@@ -276,31 +294,47 @@ __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const float2* __re
         const int y0 = (int)sy, x0 = (int)sx;
         const int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
         const float ly = sy - y0, lx = sx - x0;
-        const float2* p = in + (int64_t)b * h * w;
-        const float2 v00 = p[y0 * w + x0], v01 = p[y0 * w + x1], v10 = p[y1 * w + x0], v11 = p[y1 * w + x1];
+        const T* p = in + (int64_t)b * h * w * 2;
+        auto px = [&](int yy, int xx) {
+            const T* q = p + ((int64_t)yy * w + xx) * 2;
+            return make_float2(ld(q), ld(q + 1));
+        };
+        const float2 v00 = px(y0, x0), v01 = px(y0, x1), v10 = px(y1, x0), v11 = px(y1, x1);
         const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
         float2 r;
         r.x = scale * (w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x);
         r.y = scale * (w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y);
-        out[idx] = r;
+        st(out + 2 * idx, r.x);
+        st(out + 2 * idx + 1, r.y);
     }
 }
 
-int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, hipStream_t s) {
+int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, int dtype,
+                           hipStream_t s) {
     const int64_t total = (int64_t)B * 4 * h * w;
     const int64_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(upsample2x_flow_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s,
-                       (const float2*)in, (float2*)out, B, h, w, scale);
+    const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+    if (dtype == QPWC_F32)
+        hipLaunchKernelGGL(upsample2x_flow_kernel<float>, grid, dim3(256), 0, s, (const float*)in,
+                           (float*)out, B, h, w, scale);
+    else
+        hipLaunchKernelGGL(upsample2x_flow_kernel<__half>, grid, dim3(256), 0, s, (const __half*)in,
+                           (__half*)out, B, h, w, scale);
     return check_launch("upsample2x_flow_kernel");
 }
 
 int flow_head_param_floats() { return kFhParams; }
 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
-                     hipStream_t s) {
+                     int dtype, hipStream_t s) {
     const int tiles_x = (W + kFhTile - 1) / kFhTile, tiles_y = (H + kFhTile - 1) / kFhTile;
-    hipLaunchKernelGGL(flow_head_kernel, dim3((unsigned)(tiles_x * tiles_y * B)), dim3(256), 0, s,
-                       (const float*)z, (const float*)params, (float*)out, H, W, tiles_x, tiles_y, scale);
+    const dim3 grid((unsigned)(tiles_x * tiles_y * B));
+    if (dtype == QPWC_F32)
+        hipLaunchKernelGGL(flow_head_kernel<float>, grid, dim3(256), 0, s, (const float*)z,
+                           (const float*)params, (float*)out, H, W, tiles_x, tiles_y, scale);
+    else
+        hipLaunchKernelGGL(flow_head_kernel<__half>, grid, dim3(256), 0, s, (const __half*)z,
+                           (const float*)params, (__half*)out, H, W, tiles_x, tiles_y, scale);
     return check_launch("flow_head_kernel");
 }
 

@@ -131,8 +131,8 @@ class Upsample(_Functor):
         self.scale = scale
 
     def __call__(self, x):
-        if (self.data_format == CHANNELS_LAST and x.is_cuda and x.dtype == torch.float32 and
-                x.dim() == 4 and x.shape[3] == 2):
+        if (self.data_format == CHANNELS_LAST and x.is_cuda and
+                x.dtype in (torch.float32, torch.float16) and x.dim() == 4 and x.shape[3] == 2):
             return ops.upsample2x_flow(x, self.scale)  # flows: one HIP launch
         y = F.interpolate(self._nchw(x), scale_factor=2, mode="bilinear", align_corners=False)
         return self._fmt(y * self.scale)
@@ -150,17 +150,27 @@ class _Weighted(_Functor):
     def p(self, name):
         return self.params[self.prefix + name]
 
+    def p32(self, name):
+        """fp32 copy of a (small) parameter, converted once: the HIP epilogues take fp32
+        biases whatever the storage dtype of the activations."""
+        key = self.prefix + name + "#f32"
+        t = self.params.get(key)
+        if t is None:
+            t = self.params[key] = self.params[self.prefix + name].float().contiguous()
+        return t
+
 
 def _hip_act_ok(y_nchw, data_format):
     """The fused bias+Mish kernel applies to fp32 GPU tensors that are physically NHWC."""
-    return (data_format == CHANNELS_LAST and y_nchw.is_cuda and y_nchw.dtype == torch.float32 and
+    return (data_format == CHANNELS_LAST and y_nchw.is_cuda and
+            y_nchw.dtype in (torch.float32, torch.float16) and
             y_nchw.shape[1] % 4 == 0 and y_nchw.permute(0, 2, 3, 1).is_contiguous())
 
 
-def _bias_mish(y_nchw, bias, data_format):
+def _bias_mish(y_nchw, bias, bias32, data_format):
     """Mish(y + bias) for a bias-free library convolution output; HIP epilogue when possible."""
     if _hip_act_ok(y_nchw, data_format):
-        ops.bias_mish_(y_nchw.permute(0, 2, 3, 1), bias)
+        ops.bias_mish_(y_nchw.permute(0, 2, 3, 1), bias32)
         return y_nchw
     return F.mish(y_nchw + bias.view(1, -1, 1, 1))
 
@@ -171,7 +181,7 @@ class UpConv(_Weighted):
 
     def __call__(self, x):
         y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), None, stride=2, padding=1)
-        return self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.data_format))
+        return self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.p32("conv_up.bias"), self.data_format))
 
 
 class DownConv(_Weighted):
@@ -182,7 +192,7 @@ class DownConv(_Weighted):
         y = self._nchw(x)
         for name, stride in (("conv_a", 2), ("conv_aa", 1), ("conv_b", 1)):
             y = conv2d_same(y, self.p(name + ".weight"), None, stride)
-            y = _bias_mish(y, self.p(name + ".bias"), self.data_format)
+            y = _bias_mish(y, self.p(name + ".bias"), self.p32(name + ".bias"), self.data_format)
         return self._fmt(y)
 
 
@@ -209,7 +219,7 @@ class OptFlow(_Weighted):
             self._pw_t.append(pw.reshape(pw.shape[0], pw.shape[1]).t().contiguous())
             self._pw_b.append(self.p("feat.{}.bias".format(i)).contiguous())
             dw = self.p("feat.{}.depthwise.weight".format(i))
-            self._dw.append(dw.reshape(dw.shape[0], 9).contiguous())
+            self._dw.append(dw.reshape(dw.shape[0], 9).float().contiguous())  # fp32 in every mode
         self._head = pack_flow_head(self.p("conv.weight"), self.p("conv.bias"), self.p("norm.gamma"),
                                     self.p("norm.beta"), self.p("norm.mean"), self.p("norm.var"),
                                     self.BN_EPS, self.p("flow.weight"))
@@ -217,7 +227,7 @@ class OptFlow(_Weighted):
 
     def can_use_hip(self, sources):
         return (self.data_format == CHANNELS_LAST and self.filters[-1] == 16 and
-                all(t.is_cuda and t.dtype == torch.float32 for t in sources))
+                all(t.is_cuda and t.dtype in (torch.float32, torch.float16) for t in sources))
 
     def from_sources(self, sources):
         """OptFlow on the virtual concat of `sources` ((B,H,W,Ci) each, channels_last)."""
@@ -254,10 +264,11 @@ class OptFlow(_Weighted):
 def pack_flow_head(w1, b1, gamma, beta, mean, var, eps, wf):
     """Parameter vector of qpwc_flow_head_fwd (include/qpwc.h): w1[16][16] | b1 | bn_scale |
     bn_shift | wf[ky][kx][in][out]; BatchNorm folded to scale/shift."""
+    w1, b1, gamma, beta, mean, var, wf = (t.float() for t in (w1, b1, gamma, beta, mean, var, wf))
     bn_scale = gamma / torch.sqrt(var + eps)
     bn_shift = beta - mean * bn_scale
     return torch.cat([w1.reshape(16, 16).reshape(-1), b1.reshape(-1), bn_scale.reshape(-1),
-                      bn_shift.reshape(-1), wf.permute(2, 3, 1, 0).reshape(-1)]).contiguous().float()
+                      bn_shift.reshape(-1), wf.permute(2, 3, 1, 0).reshape(-1)]).contiguous()
 
 
 class Flow(_Weighted):

@@ -257,7 +257,7 @@ def epe(y_true, y_pred, data_format=CHANNELS_LAST):
 
 def dwconv3x3(sources, weight, mish_on_load=False):
     """Depthwise 3x3 'same' convolution over the channel-wise concatenation of 1..3
-    channels-last fp32 sources (each (B,H,W,Ci), last dim contiguous) -- the depthwise
+    channels-last fp32/fp16 sources (each (B,H,W,Ci), last dim contiguous; fp32 weights) -- the depthwise
     half of OptFlow's SeparableConv2D (qpwcnet/core/non_layers.py:223-231) without ever
     building Flow/UpFlow's concat (non_layers.py:336-338, 381-385).
     weight: (C,1,3,3) or (C,3,3) with C = sum(Ci).  -> (B,H,W,C)."""
@@ -268,8 +268,8 @@ def dwconv3x3(sources, weight, mish_on_load=False):
     chans, strides, ptrs, keep = [], [], [], []
     for i, t in enumerate(sources):
         _check_tensor("source %d" % i, t)
-        if t.dtype != torch.float32:
-            raise ValueError("dwconv3x3 is fp32 only")
+        if t.dtype != sources[0].dtype:
+            raise ValueError("dwconv3x3 sources must share one dtype")
         if tuple(t.shape[:3]) != (B, H, W):
             raise ValueError("sources must share B,H,W")
         if t.stride(3) != 1 or t.stride(1) != W * t.stride(2) or t.stride(0) != H * t.stride(1):
@@ -283,14 +283,15 @@ def dwconv3x3(sources, weight, mish_on_load=False):
     if w.shape[0] != C or w.dtype != torch.float32 or not w.is_cuda:
         raise ValueError("weight must be fp32 (C,3,3) on the device with C = {}".format(C))
     w = w.contiguous()
-    out = torch.empty((B, H, W, C), dtype=torch.float32, device=keep[0].device)
+    out = torch.empty((B, H, W, C), dtype=keep[0].dtype, device=keep[0].device)
     n = len(keep)
     c_ptrs = (ctypes.c_void_p * n)(*ptrs)
     c_ch = (ctypes.c_int * n)(*chans)
     c_st = (ctypes.c_int64 * n)(*strides)
     with torch.cuda.device(out.device), _timed("dwconv3x3", (B, H, W, C)):
         rc = _hip.lib().qpwc_dwconv3x3_fwd(c_ptrs, c_ch, c_st, n, int(bool(mish_on_load)),
-                                            w.data_ptr(), out.data_ptr(), B, H, W, _stream(out))
+                                            w.data_ptr(), out.data_ptr(), B, H, W, _DTYPES[out.dtype],
+                                            _stream(out))
     _hip.check(rc)
     return out
 
@@ -300,18 +301,18 @@ def flow_head(z, params, scale):
     tensor z (B,H,W,16): scale * conv3x3(BN(Mish(W1 Mish(z) + b1))) -> (B,H,W,2).
     params: packed fp32 vector, see include/qpwc.h / non_layers.pack_flow_head."""
     _check_tensor("z", z)
-    if z.dtype != torch.float32 or z.shape[3] != 16 or not z.is_contiguous():
-        raise ValueError("z must be a dense fp32 (B,H,W,16) tensor")
+    if z.shape[3] != 16 or not z.is_contiguous():
+        raise ValueError("z must be a dense (B,H,W,16) tensor")
     L = _hip.lib()
     if params.numel() != L.qpwc_flow_head_param_floats() or params.dtype != torch.float32 or \
             not params.is_cuda or not params.is_contiguous():
         raise ValueError("params must be a dense fp32 device vector of {} floats".format(
             L.qpwc_flow_head_param_floats()))
     B, H, W, _ = z.shape
-    out = torch.empty((B, H, W, 2), dtype=torch.float32, device=z.device)
+    out = torch.empty((B, H, W, 2), dtype=z.dtype, device=z.device)
     with torch.cuda.device(z.device), _timed("flow_head", (B, H, W, 16)):
         rc = L.qpwc_flow_head_fwd(z.data_ptr(), params.data_ptr(), out.data_ptr(), B, H, W,
-                                  float(scale), _stream(z))
+                                  float(scale), _DTYPES[z.dtype], _stream(z))
     _hip.check(rc)
     return out
 
@@ -321,15 +322,15 @@ def bias_mish_(x_nhwc, bias=None):
     the `activation='Mish'` epilogue of the reference's conv blocks (non_layers.py:196-210,
     390-449).  Returns x."""
     _check_tensor("x", x_nhwc)
-    if x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous():
-        raise ValueError("bias_mish_ needs a dense fp32 channels-last tensor")
+    if not x_nhwc.is_contiguous():
+        raise ValueError("bias_mish_ needs a dense channels-last tensor")
     C = x_nhwc.shape[-1]
     if bias is not None and (bias.numel() != C or bias.dtype != torch.float32 or not bias.is_cuda):
         raise ValueError("bias must be a fp32 device vector of {} elements".format(C))
     n = x_nhwc.numel() // C
     with torch.cuda.device(x_nhwc.device), _timed("bias_mish", tuple(x_nhwc.shape)):
         rc = _hip.lib().qpwc_bias_mish_fwd(x_nhwc.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                                            n, C, _stream(x_nhwc))
+                                            n, C, _DTYPES[x_nhwc.dtype], _stream(x_nhwc))
     _hip.check(rc)
     return x_nhwc
 
@@ -338,13 +339,13 @@ def upsample2x_flow(flo, scale=1.0):
     """scale * bilinear x2 upsampling of a channels-last fp32 flow (B,h,w,2) -- the reference's
     Upsample functor (non_layers.py:183-193) as used on flows (pwcnet.py:55,60)."""
     _check_tensor("flo", flo)
-    if flo.dtype != torch.float32 or flo.shape[3] != 2:
-        raise ValueError("upsample2x_flow takes a fp32 (B,h,w,2) tensor")
+    if flo.shape[3] != 2:
+        raise ValueError("upsample2x_flow takes a (B,h,w,2) tensor")
     f = flo.contiguous()
     B, h, w, _ = f.shape
-    out = torch.empty((B, 2 * h, 2 * w, 2), dtype=torch.float32, device=f.device)
+    out = torch.empty((B, 2 * h, 2 * w, 2), dtype=f.dtype, device=f.device)
     with torch.cuda.device(f.device), _timed("upsample2x_flow", (B, h, w, 2)):
         rc = _hip.lib().qpwc_upsample2x_flow_fwd(f.data_ptr(), out.data_ptr(), B, h, w, float(scale),
-                                                  _stream(f))
+                                                  _DTYPES[f.dtype], _stream(f))
     _hip.check(rc)
     return out

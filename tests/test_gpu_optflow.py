@@ -124,3 +124,35 @@ def test_upsample2x_flow(hw):
     torch.testing.assert_close(out, ref, rtol=0, atol=2e-6)
     out2 = non_layers.Upsample(scale=2.0, data_format="channels_last")(f.to(DEV)).cpu()
     torch.testing.assert_close(out2, ref, rtol=0, atol=2e-6)
+
+
+def test_optflow_pieces_fp16_storage():
+    """fp16 storage / fp32 arithmetic variants of the OptFlow kernels (BASELINE configs[4]);
+    bound: the fp32 oracle on the fp16-rounded inputs, output rounding only."""
+    rng = np.random.default_rng(11)
+    srcs = [_rand(rng, 2, 12, 20, c).half() for c in (81, 32, 2)]
+    w = _rand(rng, 115, 1, 3, 3)
+    for act in (False, True):
+        ref = torch_ref.depthwise3x3([s.float() for s in srcs], w, act)
+        out = ops.dwconv3x3([s.to(DEV) for s in srcs], w.to(DEV), mish_on_load=act)
+        assert out.dtype == torch.float16
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+    x = (_rand(rng, 2, 9, 11, 16) * 3).half()
+    b = _rand(rng, 16)
+    out = ops.bias_mish_(x.to(DEV).clone(), b.to(DEV)).float().cpu()
+    torch.testing.assert_close(out, torch_ref.mish(x.float() + b), rtol=2e-3, atol=2e-3)
+    f = _rand(rng, 2, 6, 9, 2).half()
+    up = ops.upsample2x_flow(f.to(DEV), 2.0).float().cpu()
+    torch.testing.assert_close(up, net_ref.RefNet.upsample(f.float(), 2.0), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 256, 32), (2, 64, 128, 64), (2, 19, 37, 32)])
+def test_cost_volume_fp16_matrix_core_kernel(shape):
+    """v_mfma_f32_16x16x32_f16 path: exact fp16 products, fp32 accumulation."""
+    from oracle import c_ref
+    rng = np.random.default_rng(shape[1])
+    a = rng.standard_normal(shape).astype(np.float16)
+    b = rng.standard_normal(shape).astype(np.float16)
+    out = ops.cost_volume(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).float().cpu().numpy()
+    ref = c_ref.cost_volume(a.astype(np.float32), b.astype(np.float32))
+    np.testing.assert_allclose(out, ref, rtol=1e-3, atol=1e-3)
