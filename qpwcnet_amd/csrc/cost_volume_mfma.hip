@@ -40,24 +40,104 @@ constexpr int kFramePS = 148;                 // floats per pixel frame (144 + 4
 constexpr int kFrameFloats = 16 * kFramePS;   // per wave
 constexpr int kRowStep = 4 * kFramePS + 12;   // frame offset of the next tile row (py+1, same px)
 
+// Frame window -> output rows of one 4x4 tile, for ONE wave that owns the whole frame.
+// The CU's vector-memory pipeline is what this kernel family saturates (s_memtime
+// stamps: a third of a wave's life was spent waiting to ISSUE its 24 dword stores), so
+// the dense case stores 4 consecutive output floats per lane: a tile row of 324 floats
+// is 81 x 16 B, rows are 16-byte aligned when W % 4 == 0, and a wave needs 8 store
+// instructions instead of 24.  All LDS reads are issued before the first use.
+template <typename T>
+__device__ __forceinline__ void store_tile(const float* fr, T* ob, int lane, int x0, int y0, int H,
+                                           int W, int out_pix_stride, float slope, float inv_c,
+                                           float cf) {
+    const int row_stride = W * out_pix_stride;
+    if (out_pix_stride == 81 && (W & 3) == 0 && x0 + 4 <= W && y0 + 4 <= H) {  // wave-uniform
+        // lane owns elements 4*q .. 4*q+3 of the 324-float row, q = lane (+64 for lanes 0..16)
+        int foff[2][4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = lane + 64 * it;
+            const int qq = q < 81 ? q : 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = 4 * qq + c;
+                const int epx = e / 81, k = e - 81 * epx;
+                const int ky = k / 9, kx = k - 9 * ky;
+                foff[it][c] = epx * kFramePS + epx + ky * 12 + kx;
+            }
+        }
+        float v[4][2][4];
+#pragma unroll
+        for (int row = 0; row < 4; ++row)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[row][it][c] = fr[foff[it][c] + row * kRowStep];
+        const bool second = lane < 17;  // float4 64..80
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            T* orow = ob + (int64_t)row * row_stride;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                float4 o;
+                if (inv_c > 0.f) {
+                    o = make_float4(lrelu(v[row][it][0] * inv_c, slope), lrelu(v[row][it][1] * inv_c, slope),
+                                    lrelu(v[row][it][2] * inv_c, slope), lrelu(v[row][it][3] * inv_c, slope));
+                } else {
+                    o = make_float4(lrelu(v[row][it][0] / cf, slope), lrelu(v[row][it][1] / cf, slope),
+                                    lrelu(v[row][it][2] / cf, slope), lrelu(v[row][it][3] / cf, slope));
+                }
+                if (it == 0 || second) st4(orow + 4 * (lane + 64 * it), o);
+            }
+        }
+        return;
+    }
+    // general case: strided output (concat buffer), ragged image edge
+    int foff[6];
+    unsigned goff[6];
+    int epx[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int e = lane + 64 * s;     // element of the 4 px * 81 row
+        const int ee = e < 324 ? e : 0;  // s == 5 covers elements 320..323 only
+        epx[s] = ee / 81;
+        const int k = ee - 81 * epx[s];
+        const int ky = k / 9, kx = k - 9 * ky;
+        foff[s] = epx[s] * kFramePS + epx[s] + ky * 12 + kx;  // window origin (py, px) + (ky, kx)
+        goff[s] = (unsigned)(epx[s] * out_pix_stride + k);
+    }
+    float v[4][6];
+#pragma unroll
+    for (int row = 0; row < 4; ++row)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) v[row][s] = fr[foff[s] + row * kRowStep];
+    const bool tail = lane < 4;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        T* orow = ob + (int64_t)row * row_stride;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const float m = inv_c > 0.f ? v[row][s] * inv_c : v[row][s] / cf;
+            if ((s < 5 || tail) && y0 + row < H && x0 + epx[s] < W) st(orow + goff[s], lrelu(m, slope));
+        }
+    }
+}
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size we accept: the load returns 0
 
-// Operand fetch, two stages:
-//  (1) COALESCED raw buffer loads (descriptor in SGPRs + 32-bit lane byte offset +
-//      scalar step offset; offsets beyond the descriptor return zero = the
-//      reference's ZeroPadding2D for free).  Load layout: lane l -> pixel l>>2 of the
-//      4x4 block, quarter q = l&3, so the 4 adjacent lanes of a pixel read 64
-//      contiguous bytes per instruction (the texture addresser merges adjacent lanes
-//      only: with the matrix-core layout, where adjacent lanes are adjacent PIXELS,
-//      every lane was its own L1 access and the kernel was TA-bound);
+// Operand fetch of the per-wave kernel, two stages:
+//  (1) COALESCED raw buffer loads (descriptor in SGPRs + 32-bit lane byte offset + scalar
+//      step offset; offsets beyond the descriptor return zero = ZeroPadding2D for free).
+//      Load layout: lane l -> pixel l>>2 of the 4x4 block, quarter l&3, so the 4 adjacent
+//      lanes of a pixel read 64 contiguous bytes per instruction (the texture addresser
+//      merges adjacent lanes only: in matrix-core layout, where adjacent lanes are adjacent
+//      PIXELS, every lane was its own L1 access and the kernel was TA-bound);
 //  (2) one ds_bpermute per register moves the data to the matrix-core layout
 //      (lane l -> pixel l&15, k-slot l>>4): source lane 4*(l&15) + (l>>4).
-// Channel order inside a step is whatever falls out (k-slot g, k-step (h,e) <->
-// channel step*CSTEP + 16h + 4g + e for fp32 CPL=8); prv and nxt use the same map,
-// and the sum over channels does not care.
+// prv and nxt use the same channel-to-k map, and the sum over channels does not care.
 template <int CPL, typename T>
 struct OperandLoad;
 template <>
@@ -383,27 +463,8 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
 
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
     if (x0 >= W || y0 >= H) return;
-    const bool use_mul = inv_c > 0.f;
-    const float scale = use_mul ? inv_c : (float)C;
     float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
-    const int row_stride = W * out_pix_stride;
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int e = lane + 64 * s;
-        const int epx = e / 81, k = e - 81 * epx;
-        const int ky = k / 9, kx = k - 9 * ky;
-        const bool e_ok = e < 324 && x0 + epx < W;
-        const int foff = epx * kFramePS + epx + ky * 12 + kx;
-        const unsigned go = (unsigned)(epx * out_pix_stride + k);
-#pragma unroll
-        for (int row = 0; row < 4; ++row) {
-            if (e_ok && y0 + row < H) {
-                float v = fr[foff + row * kRowStep];
-                v = use_mul ? v * scale : v / scale;
-                ob[(int64_t)row * row_stride + go] = lrelu(v, slope);
-            }
-        }
-    }
+    store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C);
 }
 
 // ---------------------------------------------------------------------------
@@ -496,27 +557,8 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
 
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
     if (x0 >= W || y0 >= H) return;
-    const bool use_mul = inv_c > 0.f;
-    const float scale = use_mul ? inv_c : (float)C;
     __half* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
-    const int row_stride = W * out_pix_stride;
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int e = lane + 64 * s;
-        const int epx = e / 81, k = e - 81 * epx;
-        const int ky = k / 9, kx = k - 9 * ky;
-        const bool e_ok = e < 324 && x0 + epx < W;
-        const int foff = epx * kFramePS + epx + ky * 12 + kx;
-        const unsigned go = (unsigned)(epx * out_pix_stride + k);
-#pragma unroll
-        for (int row = 0; row < 4; ++row) {
-            if (e_ok && y0 + row < H) {
-                float v = fr[foff + row * kRowStep];
-                v = use_mul ? v * scale : v / scale;
-                ob[(int64_t)row * row_stride + go] = __float2half_rn(lrelu(v, slope));
-            }
-        }
-    }
+    store_tile<__half>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C);
 }
 
 static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int B, int H, int W, int C,
