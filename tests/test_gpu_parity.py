@@ -313,3 +313,33 @@ def test_full_network_fp16_config5():
         e = float(torch_ref.epe_error(a.float().cpu(), b))
         mag = float(torch.linalg.vector_norm(b, dim=-1).mean())
         assert e < 0.05 * max(mag, 0.1), "level {}: EPE {:.3e} vs |flow| {:.3e}".format(lvl, e, mag)
+
+
+@pytest.mark.parametrize("shape", [(32, 36, 52, 32), (40, 30, 44, 64), (3, 19, 37, 32), (5, 7, 9, 64),
+                                   (2, 12, 20, 16), (1, 4, 4, 256)])
+def test_matrix_core_kernels_ragged_edges(shape):
+    """H, W not multiples of the 4x4 tile / 8x8 region: workgroup-shared kernel (many
+    regions) and per-wave split-K kernel (few tiles), zero padding at every border."""
+    rng = np.random.default_rng(shape[1] * 100 + shape[2])
+    prv = rng.standard_normal(shape).astype(np.float32)
+    nxt = rng.standard_normal(shape).astype(np.float32)
+    out = ops.cost_volume(gpu(prv), gpu(nxt)).cpu().numpy()
+    np.testing.assert_allclose(out, c_ref.cost_volume(prv, nxt), rtol=0, atol=TOL)
+    # fp16 storage on the same shapes (fp16 matrix cores where eligible)
+    ph, nh = prv.astype(np.float16), nxt.astype(np.float16)
+    outh = ops.cost_volume(gpu(ph), gpu(nh)).float().cpu().numpy()
+    refh = c_ref.cost_volume(ph.astype(np.float32), nh.astype(np.float32))
+    np.testing.assert_allclose(outh, refh, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 64, 32), (2, 16, 32, 64)])
+def test_matrix_core_kernels_strided_output(shape):
+    """81 channels written at a channel offset of a wider buffer (the concat target)."""
+    rng = np.random.default_rng(7)
+    prv = rng.standard_normal(shape).astype(np.float32)
+    nxt = rng.standard_normal(shape).astype(np.float32)
+    B, H, W, C = shape
+    feat = torch.full((B, H, W, 81 + C + 2), 7.0, device=DEV)
+    ops.cost_volume_into(gpu(prv), gpu(nxt), feat, 0)
+    np.testing.assert_allclose(feat[..., :81].cpu().numpy(), c_ref.cost_volume(prv, nxt), atol=TOL)
+    assert bool((feat[..., 81:] == 7.0).all())

@@ -110,3 +110,22 @@ def test_synthetic_frames():
 
 def test_version():
     assert qpwcnet_amd.__version__
+
+
+def test_keras_layout_round_trip(tmp_path):
+    from qpwcnet_amd import weights as W
+    w = synth.make_weights(42)
+    k = W.to_keras_layout(w)
+    assert k["enc.0.conv_a.weight"].shape == (3, 3, 3, 16)              # (kh, kw, in, out)
+    assert k["flow.flow.feat.0.depthwise.weight"].shape == (3, 3, 593, 1)
+    assert k["flow.flow.feat.0.pointwise.weight"].shape == (1, 1, 593, 128)
+    assert k["dec.0.conv_up.weight"].shape == (4, 4, 128, 256)          # (kh, kw, out, in)
+    back = W.from_keras_layout(k)
+    assert all(np.array_equal(back[n], w[n]) for n in w)
+    # one tap, checked by hand: Keras kernel[ky,kx,i,o] == torch weight[o,i,ky,kx]
+    assert k["enc.1.conv_b.weight"][2, 0, 5, 7] == w["enc.1.conv_b.weight"][7, 5, 2, 0]
+    assert k["dec.1.conv_up.weight"][1, 3, 9, 4] == w["dec.1.conv_up.weight"][4, 9, 1, 3]
+    p = tmp_path / "w.npz"
+    W.save_npz(str(p), w)
+    again = W.load_npz(str(p))
+    assert all(np.array_equal(again[n], w[n]) for n in w)
