@@ -116,6 +116,14 @@ int qpwc_epe_workspace_floats(void);
 int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* workspace,
                  int B, int H, int W, int layout, void* stream);
 
+/* Multi-scale form (FlowMseLoss.call, qpwcnet/train/loss.py:56-67): the EPE of n_levels
+ * (<= 8) channels-last fp32 flow pairs y_true[i], y_pred[i] with n_pixels[i] = B*h_i*w_i
+ * each, in two launches.  out_means: n_levels floats; workspace:
+ * >= qpwc_epe_multi_workspace_floats() floats. */
+int qpwc_epe_multi_workspace_floats(void);
+int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
+                       int n_levels, void* out_means, void* workspace, void* stream);
+
 /* ---- OptFlow block, the step right after the cost volume at every level
  * (reference qpwcnet/core/non_layers.py:213-273) ---------- */
 

@@ -25,7 +25,7 @@ SYMBOLS = (
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_bias_mish_fwd",
-    "qpwc_upsample2x_flow_fwd",
+    "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd",
 )
 
 _lib = None
@@ -89,6 +89,10 @@ def lib():
     L.qpwc_bias_mish_fwd.restype = ci
     L.qpwc_upsample2x_flow_fwd.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp]
     L.qpwc_upsample2x_flow_fwd.restype = ci
+    L.qpwc_epe_multi_workspace_floats.argtypes = []
+    L.qpwc_epe_multi_workspace_floats.restype = ci
+    L.qpwc_epe_multi_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64), ci, vp, vp, vp]
+    L.qpwc_epe_multi_fwd.restype = ci
     _lib = L
     return L
 

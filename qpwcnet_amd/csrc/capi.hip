@@ -35,6 +35,9 @@ int epe_workspace_floats();
 int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int H, int W,
                int layout, hipStream_t s);
 
+int epe_multi_workspace_floats();
+int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, int n_levels,
+                     float* out, float* ws, hipStream_t s);
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
                      int act, const void* weight, void* out, int B, int H, int W, int dtype,
                      hipStream_t s);
@@ -249,6 +252,23 @@ int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, flo
     if (overlaps(out, (size_t)B * 4 * h * w * 2 * es, in, (size_t)B * h * w * 2 * es))
         return fail(QPWC_E_ALIAS, "out overlaps in");
     return upsample2x_flow_launch(in, out, B, h, w, scale, dtype, (hipStream_t)stream);
+}
+
+int qpwc_epe_multi_workspace_floats(void) { return epe_multi_workspace_floats(); }
+
+int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
+                       int n_levels, void* out_means, void* workspace, void* stream) {
+    if (!y_true || !y_pred || !n_pixels || !out_means || !workspace)
+        return fail(QPWC_E_NULL, "null pointer argument");
+    if (n_levels < 1 || n_levels > 8) return fail(QPWC_E_SHAPE, "n_levels %d outside [1,8]", n_levels);
+    for (int i = 0; i < n_levels; ++i) {
+        if (!y_true[i] || !y_pred[i]) return fail(QPWC_E_NULL, "null flow pointer at level %d", i);
+        if (n_pixels[i] <= 0) return fail(QPWC_E_SHAPE, "level %d has no pixels", i);
+        if ((uintptr_t)y_true[i] % 8 || (uintptr_t)y_pred[i] % 8)
+            return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte aligned");
+    }
+    return epe_multi_launch(y_true, y_pred, n_pixels, n_levels, (float*)out_means, (float*)workspace,
+                            (hipStream_t)stream);
 }
 
 }  // extern "C"

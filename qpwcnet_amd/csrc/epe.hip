@@ -63,6 +63,60 @@ __global__ __launch_bounds__(kEpeThreads) void epe_final_kernel(const float* __r
     if (threadIdx.x == 0) *out = s * inv_npix;
 }
 
+// All levels of the multi-scale EPE (FlowMseLoss, qpwcnet/train/loss.py:56-67) in two
+// launches instead of 2 per level: blockIdx.y = level, blockIdx.x = partial sum.
+constexpr int kEpeMaxLevels = 8;
+constexpr int kEpeMultiBlocks = 64;
+struct EpeLevels {
+    const float* a[kEpeMaxLevels];
+    const float* b[kEpeMaxLevels];
+    int64_t npix[kEpeMaxLevels];
+};
+
+__global__ __launch_bounds__(kEpeThreads) void epe_multi_partial_kernel(EpeLevels lv,
+                                                                       float* __restrict__ partial) {
+    __shared__ float red[kEpeThreads / 64];
+    const int l = blockIdx.y;
+    const float2* a = reinterpret_cast<const float2*>(lv.a[l]);
+    const float2* b = reinterpret_cast<const float2*>(lv.b[l]);
+    const int64_t n = lv.npix[l];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float2 va = a[i], vb = b[i];
+        const float dx = va.x - vb.x, dy = va.y - vb.y;
+        s += sqrtf(dx * dx + dy * dy);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[l * kEpeMultiBlocks + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(64) void epe_multi_final_kernel(const float* __restrict__ partial,
+                                                             float* __restrict__ out, EpeLevels lv) {
+    const int l = blockIdx.x;
+    float s = partial[l * kEpeMultiBlocks + threadIdx.x];  // kEpeMultiBlocks == 64 == one wave
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[l] = s / (float)lv.npix[l];
+}
+
+int epe_multi_workspace_floats() { return kEpeMaxLevels * kEpeMultiBlocks; }
+
+int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, int n_levels,
+                     float* out, float* ws, hipStream_t s) {
+    EpeLevels lv;
+    for (int i = 0; i < kEpeMaxLevels; ++i) {
+        lv.a[i] = i < n_levels ? (const float*)a[i] : nullptr;
+        lv.b[i] = i < n_levels ? (const float*)b[i] : nullptr;
+        lv.npix[i] = i < n_levels ? npix[i] : 0;
+    }
+    hipLaunchKernelGGL(epe_multi_partial_kernel, dim3(kEpeMultiBlocks, n_levels), dim3(kEpeThreads), 0, s,
+                       lv, ws);
+    int rc = check_launch("epe_multi_partial_kernel");
+    if (rc != QPWC_OK) return rc;
+    hipLaunchKernelGGL(epe_multi_final_kernel, dim3(n_levels), dim3(64), 0, s, ws, out, lv);
+    return check_launch("epe_multi_final_kernel");
+}
+
 int epe_workspace_floats() { return kEpeBlocks; }
 
 int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int H, int W,

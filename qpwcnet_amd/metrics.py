@@ -25,4 +25,6 @@ def multiscale_ground_truth(flow_gt, shapes, data_format=CHANNELS_LAST):
 
 def per_level_epe(flows_true, flows_pred, data_format=CHANNELS_LAST):
     """-> float32 tensor [n_levels] on the flows' device (HIP reduction kernel)."""
+    if data_format == CHANNELS_LAST and len(flows_true) <= 8:
+        return ops.epe_multi(flows_true, flows_pred)  # all levels in two launches
     return torch.stack([ops.epe(t, p.float(), data_format) for t, p in zip(flows_true, flows_pred)])

@@ -349,3 +349,33 @@ def upsample2x_flow(flo, scale=1.0):
                                                   _DTYPES[f.dtype], _stream(f))
     _hip.check(rc)
     return out
+
+
+def epe_multi(flows_true, flows_pred):
+    """Per-level EPE of up to 8 channels-last fp32 flow pairs in two launches
+    (FlowMseLoss, qpwcnet/train/loss.py:56-67) -> float32 tensor [n_levels]."""
+    import ctypes
+    n = len(flows_true)
+    if n != len(flows_pred) or not 1 <= n <= 8:
+        raise ValueError("epe_multi takes 1..8 (true, pred) pairs")
+    keep, pa, pb, npix = [], [], [], []
+    for i, (a, b) in enumerate(zip(flows_true, flows_pred)):
+        _check_tensor("y_true[%d]" % i, a)
+        _check_tensor("y_pred[%d]" % i, b)
+        if a.shape != b.shape or a.shape[3] != 2:
+            raise ValueError("level {}: shapes {} / {}".format(i, tuple(a.shape), tuple(b.shape)))
+        a, b = a.float().contiguous(), b.float().contiguous()
+        keep += [a, b]
+        pa.append(a.data_ptr())
+        pb.append(b.data_ptr())
+        npix.append(a.numel() // 2)
+    dev = keep[0].device
+    L = _hip.lib()
+    ws = torch.empty(L.qpwc_epe_multi_workspace_floats(), dtype=torch.float32, device=dev)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.qpwc_epe_multi_fwd((ctypes.c_void_p * n)(*pa), (ctypes.c_void_p * n)(*pb),
+                                  (ctypes.c_int64 * n)(*npix), n, out.data_ptr(), ws.data_ptr(),
+                                  _stream(out))
+    _hip.check(rc)
+    return out

@@ -343,3 +343,16 @@ def test_matrix_core_kernels_strided_output(shape):
     ops.cost_volume_into(gpu(prv), gpu(nxt), feat, 0)
     np.testing.assert_allclose(feat[..., :81].cpu().numpy(), c_ref.cost_volume(prv, nxt), atol=TOL)
     assert bool((feat[..., 81:] == 7.0).all())
+
+
+def test_epe_multi_level():
+    from qpwcnet_amd import metrics
+    rng = np.random.default_rng(12)
+    shapes = [(3, 8, 16), (3, 16, 32), (3, 33, 47), (3, 128, 256)]
+    a = [rng.standard_normal(s + (2,)).astype(np.float32) for s in shapes]
+    b = [rng.standard_normal(s + (2,)).astype(np.float32) for s in shapes]
+    out = ops.epe_multi([gpu(x) for x in a], [gpu(x) for x in b]).cpu().numpy()
+    ref = np.asarray([c_ref.epe(x, y) for x, y in zip(a, b)])
+    np.testing.assert_allclose(out, ref, rtol=1e-5)
+    out2 = metrics.per_level_epe([gpu(x) for x in a], [gpu(x) for x in b]).cpu().numpy()
+    np.testing.assert_allclose(out2, ref, rtol=1e-5)
