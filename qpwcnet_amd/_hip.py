@@ -26,6 +26,7 @@ SYMBOLS = (
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_bias_mish_fwd",
     "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd",
+    "qpwc_sepconv3x3_fwd",
 )
 
 _lib = None
@@ -93,6 +94,9 @@ def lib():
     L.qpwc_epe_multi_workspace_floats.restype = ci
     L.qpwc_epe_multi_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64), ci, vp, vp, vp]
     L.qpwc_epe_multi_fwd.restype = ci
+    L.qpwc_sepconv3x3_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(i64),
+                                      ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.qpwc_sepconv3x3_fwd.restype = ci
     _lib = L
     return L
 

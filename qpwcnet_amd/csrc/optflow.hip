@@ -32,6 +32,8 @@ __device__ __forceinline__ float mishf(float x) {
     return x > 20.0f ? x : m;
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 struct DwSrc {
     const void* ptr[3];
     int ch[3];          // channels taken from each source (0 = unused)
@@ -158,6 +160,159 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
     else
         dwconv_dispatch<__half>(d, act, weight, out, H, W, C, strips, wq, grid, s);
     return check_launch("dwconv3x3_kernel");
+}
+
+// ---------------------------------------------------------------------------
+// sepconv3x3_fused: the WHOLE SeparableConv2D (depthwise 3x3 -> pointwise 1x1 + bias,
+// pre-activation output) in one launch, fp32.  The depthwise result never goes to HBM:
+// per 16-channel chunk a workgroup (4 waves, 8x8 pixel tile) stages the 10x10 halo tile
+// of the (virtually concatenated, optionally Mish-activated) input in LDS, computes the
+// depthwise outputs into an LDS operand tile, and feeds them with the matching slice of
+// the pointwise weights to v_mfma_f32_16x16x4_f32 (rows = output channels, cols = the
+// wave's 16 pixels).  k-slot g of a lane owns channels 4g..4g+3 of the chunk, so every
+// operand is one ds_read_b128.
+// pointwise weights: (F, Cpad) row-major with Cpad = ceil(C/16)*16, zero padded.
+constexpr int kScKC = 16;               // channels per chunk
+constexpr int kScTile = 8;              // 8x8 pixels per workgroup
+constexpr int kScHalo = kScTile + 2;
+constexpr int kScLd = 20;               // padded row stride (floats) of the operand tiles
+
+template <int F, bool ACT>
+__global__ __launch_bounds__(256) void sepconv3x3_fused_kernel(
+    DwSrc src, const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y) {
+    constexpr int NFT = F / 16;
+    __shared__ __attribute__((aligned(16))) float in_s[kScHalo * kScHalo * kScKC];
+    __shared__ __attribute__((aligned(16))) float y_s[64 * kScLd];
+    __shared__ __attribute__((aligned(16))) float w_s[F * kScLd];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kScTile, Y0 = ty * kScTile;
+    const int n = lane & 15, g = lane >> 4;
+
+    f32x4v acc[NFT];
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const int dc = tid & 15;       // channel of this thread inside a chunk (staging + depthwise)
+    const int dp = tid >> 4;       // 0..15
+    for (int c0 = 0; c0 < cpad; c0 += kScKC) {
+        // ---- stage the halo tile of this chunk (Mish applied once per element) ---------
+        const int c = c0 + dc;
+        const float* p = nullptr;
+        int64_t ps = 0;
+        if (c < C) {
+            int cc;
+            if (c < src.ch[0]) {
+                p = (const float*)src.ptr[0]; ps = src.stride[0]; cc = c;
+            } else if (c < src.ch[0] + src.ch[1]) {
+                p = (const float*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
+            } else {
+                p = (const float*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
+            }
+            p += (int64_t)b * H * W * ps + cc;
+        }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int hp = dp + 16 * it;  // halo pixel 0..99
+            if (hp < kScHalo * kScHalo) {
+                const int hy = hp / kScHalo, hx = hp - hy * kScHalo;
+                const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+                float v = 0.0f;
+                if (p && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    v = p[((int64_t)gy * W + gx) * ps];
+                    if (ACT) v = mishf(v);
+                }
+                in_s[hp * kScKC + dc] = v;
+            }
+        }
+        // pointwise weights of this chunk: w_s[f][0..15] = pw[f][c0..c0+15]
+        for (int i = tid; i < F * 4; i += 256) {
+            const int f = i >> 2, q = i & 3;
+            *reinterpret_cast<float4*>(w_s + f * kScLd + 4 * q) =
+                *reinterpret_cast<const float4*>(pw + (int64_t)f * cpad + c0 + 4 * q);
+        }
+        float wk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = c < C ? dw[c * 9 + k] : 0.0f;
+        __syncthreads();
+        // ---- depthwise: 4 pixels per thread for channel dc ----------------------------
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = dp + 16 * j;  // 0..63
+            const int py = pix >> 3, px = pix & 7;
+            float a = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    a = fmaf(wk[ky * 3 + kx], in_s[((py + ky) * kScHalo + px + kx) * kScKC + dc], a);
+            y_s[pix * kScLd + dc] = a;
+        }
+        __syncthreads();
+        // ---- pointwise on the matrix cores: D[f][px] += W[f][k] * y[px][k] --------------
+        const f32x4v yv = *reinterpret_cast<const f32x4v*>(y_s + (16 * wave + n) * kScLd + 4 * g);
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            const f32x4v wv = *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScLd + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], yv[t], acc[ft], 0, 0, 0);
+        }
+        __syncthreads();  // operand tiles are rewritten by the next chunk
+    }
+    // ---- bias + store: lane = pixel n of the wave's 16, 4 consecutive outputs 4g..4g+3 ----
+    const int pix = 16 * wave + n;
+    const int gy = Y0 + (pix >> 3), gx = X0 + (pix & 7);
+    if (gy < H && gx < W) {
+        float* o = out + ((int64_t)(b * H + gy) * W + gx) * F;
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+            *reinterpret_cast<float4*>(o + 16 * ft + 4 * g) =
+                make_float4(acc[ft][0] + bv.x, acc[ft][1] + bv.y, acc[ft][2] + bv.z, acc[ft][3] + bv.w);
+        }
+    }
+}
+
+template <int F>
+static void sepconv_dispatch(const DwSrc& d, int act, const float* dw, const float* pw, const float* bias,
+                             float* out, int H, int W, int C, int cpad, int tiles_x, int tiles_y,
+                             dim3 grid, hipStream_t s) {
+    if (act)
+        hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, true>), grid, dim3(256), 0, s, d, dw, pw, bias, out,
+                           H, W, C, cpad, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, false>), grid, dim3(256), 0, s, d, dw, pw, bias, out,
+                           H, W, C, cpad, tiles_x, tiles_y);
+}
+
+int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
+                      int act, const void* dw, const void* pw, const void* bias, void* out, int B, int H,
+                      int W, int F, hipStream_t s) {
+    DwSrc d;
+    int C = 0;
+    for (int i = 0; i < 3; ++i) {
+        d.ptr[i] = i < n_src ? srcs[i] : nullptr;
+        d.ch[i] = i < n_src ? chans[i] : 0;
+        d.stride[i] = i < n_src ? strides[i] : 0;
+        C += d.ch[i];
+    }
+    const int cpad = (C + kScKC - 1) / kScKC * kScKC;
+    const int tiles_x = (W + kScTile - 1) / kScTile, tiles_y = (H + kScTile - 1) / kScTile;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * B));
+    const float *fdw = (const float*)dw, *fpw = (const float*)pw, *fb = (const float*)bias;
+    switch (F) {
+        case 128: sepconv_dispatch<128>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 64: sepconv_dispatch<64>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 32: sepconv_dispatch<32>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 16: sepconv_dispatch<16>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        default: set_error("sepconv3x3: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
+    }
+    return check_launch("sepconv3x3_fused_kernel");
 }
 
 // ---------------------------------------------------------------------------

@@ -202,6 +202,10 @@ class OptFlow(_Weighted):
     times sqrt(h^2 + w^2) of the input's spatial size."""
 
     BN_EPS = 1e-3
+    # class-wide switch: fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd) instead of
+    # dwconv + library GEMM.  Measured slower at every level so far (25 TF vs 75 TF for the
+    # GEMM half), so it is off by default and kept for the tests / later tuning.
+    fused_sepconv = False
 
     def __init__(self, params, prefix, filters=(128, 64, 32, 16), scale=None, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
@@ -220,6 +224,9 @@ class OptFlow(_Weighted):
             self._pw_b.append(self.p("feat.{}.bias".format(i)).contiguous())
             dw = self.p("feat.{}.depthwise.weight".format(i))
             self._dw.append(dw.reshape(dw.shape[0], 9).float().contiguous())  # fp32 in every mode
+        self._pw_pad = [ops.pad_pointwise(self.p("feat.{}.pointwise.weight".format(i)))
+                        for i in range(len(self.filters))]
+        self._pw_b32 = [b.float().contiguous() for b in self._pw_b]
         self._head = pack_flow_head(self.p("conv.weight"), self.p("conv.bias"), self.p("norm.gamma"),
                                     self.p("norm.beta"), self.p("norm.mean"), self.p("norm.var"),
                                     self.BN_EPS, self.p("flow.weight"))
@@ -237,9 +244,14 @@ class OptFlow(_Weighted):
         B, H, W = sources[0].shape[:3]
         scale = self.scale if self.scale is not None else float(H ** 2 + W ** 2) ** 0.5
         z = None
+        fused = self.fused_sepconv and sources[0].dtype == torch.float32
         for i in range(len(self.filters)):
-            y = ops.dwconv3x3(sources if i == 0 else [z], self._dw[i], mish_on_load=i > 0)
-            z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1), self._pw_t[i]).view(B, H, W, -1)
+            src = sources if i == 0 else [z]
+            if fused:  # depthwise + pointwise + bias in one launch, depthwise result stays on chip
+                z = ops.sepconv3x3(src, self._dw[i], self._pw_pad[i], self._pw_b32[i], mish_on_load=i > 0)
+            else:
+                y = ops.dwconv3x3(src, self._dw[i], mish_on_load=i > 0)
+                z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1), self._pw_t[i]).view(B, H, W, -1)
         return ops.flow_head(z, self._head, scale)
 
     def __call__(self, inputs):

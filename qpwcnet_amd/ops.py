@@ -379,3 +379,60 @@ def epe_multi(flows_true, flows_pred):
                                   _stream(out))
     _hip.check(rc)
     return out
+
+
+def _dw_sources(sources):
+    """-> (kept tensors, ctypes pointer/channel/stride arrays, B, H, W, C) for 1..3 sources."""
+    import ctypes
+    if not 1 <= len(sources) <= 3:
+        raise ValueError("1..3 sources")
+    B, H, W = sources[0].shape[:3]
+    chans, strides, ptrs, keep = [], [], [], []
+    for i, t in enumerate(sources):
+        _check_tensor("source %d" % i, t)
+        if t.dtype != sources[0].dtype or tuple(t.shape[:3]) != (B, H, W):
+            raise ValueError("sources must share dtype and B,H,W")
+        if t.stride(3) != 1 or t.stride(1) != W * t.stride(2) or t.stride(0) != H * t.stride(1):
+            t = t.contiguous()
+        keep.append(t)
+        chans.append(t.shape[3])
+        strides.append(t.stride(2))
+        ptrs.append(t.data_ptr())
+    n = len(keep)
+    return keep, (ctypes.c_void_p * n)(*ptrs), (ctypes.c_int * n)(*chans), (ctypes.c_int64 * n)(*strides), \
+        B, H, W, sum(chans)
+
+
+def pad_pointwise(pw):
+    """(F, C[,1,1]) pointwise kernel -> dense fp32 (F, ceil(C/16)*16), zero padded: the
+    layout qpwc_sepconv3x3_fwd takes."""
+    pw = pw.reshape(pw.shape[0], -1).float()
+    F_, C = pw.shape
+    cpad = (C + 15) // 16 * 16
+    out = torch.zeros((F_, cpad), dtype=torch.float32, device=pw.device)
+    out[:, :C] = pw
+    return out
+
+
+def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False):
+    """SeparableConv2D(3x3,'same') without its activation, fused (fp32): depthwise 3x3 over
+    the virtual concat of 1..3 channels-last sources, pointwise 1x1 + bias on the matrix
+    cores (qpwcnet/core/non_layers.py:223-231).  pw_padded from pad_pointwise().
+    -> pre-activation (B,H,W,F)."""
+    keep, c_ptrs, c_ch, c_st, B, H, W, C = _dw_sources(sources)
+    if keep[0].dtype != torch.float32:
+        raise ValueError("sepconv3x3 is fp32 only")
+    F_ = pw_padded.shape[0]
+    w = dw.reshape(-1, 9)
+    if w.shape[0] != C or pw_padded.shape[1] != (C + 15) // 16 * 16 or bias.numel() != F_:
+        raise ValueError("weight shapes do not match C = {}".format(C))
+    for t in (w, pw_padded, bias):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("weights must be dense fp32 device tensors")
+    out = torch.empty((B, H, W, F_), dtype=torch.float32, device=keep[0].device)
+    with torch.cuda.device(out.device), _timed("sepconv3x3", (B, H, W, C, F_)):
+        rc = _hip.lib().qpwc_sepconv3x3_fwd(c_ptrs, c_ch, c_st, len(keep), int(bool(mish_on_load)),
+                                             w.data_ptr(), pw_padded.data_ptr(), bias.data_ptr(),
+                                             out.data_ptr(), B, H, W, F_, _stream(out))
+    _hip.check(rc)
+    return out

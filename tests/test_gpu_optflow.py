@@ -156,3 +156,42 @@ def test_cost_volume_fp16_matrix_core_kernel(shape):
     out = ops.cost_volume(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).float().cpu().numpy()
     ref = c_ref.cost_volume(a.astype(np.float32), b.astype(np.float32))
     np.testing.assert_allclose(out, ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("chans,F", [((81, 32, 2), 128), ((81, 256, 256), 128), ((128,), 64), ((64,), 32),
+                                     ((32,), 16), ((7, 3), 16)])
+@pytest.mark.parametrize("hw", [(8, 16), (19, 37)])
+@pytest.mark.parametrize("act", [False, True])
+def test_sepconv3x3_fused(chans, F, hw, act):
+    """Fused SeparableConv2D (depthwise on chip -> matrix-core pointwise + bias) vs the oracle."""
+    rng = np.random.default_rng(sum(chans) + F + hw[0])
+    H, W = hw
+    C = sum(chans)
+    srcs = [_rand(rng, 2, H, W, c) for c in chans]
+    dw = _rand(rng, C, 1, 3, 3)
+    pw = _rand(rng, F, C, 1, 1) / np.sqrt(C)
+    bias = _rand(rng, F)
+    y = torch_ref.depthwise3x3(srcs, dw, act)
+    ref = torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw, bias).permute(0, 2, 3, 1)
+    out = ops.sepconv3x3([s.to(DEV) for s in srcs], dw.to(DEV), ops.pad_pointwise(pw.to(DEV)),
+                         bias.to(DEV), mish_on_load=act).cpu()
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out, ref, rtol=0, atol=5e-5)
+
+
+def test_optflow_fused_and_unfused_sepconv_agree():
+    hw = (32, 64)
+    weights = synth.make_weights(42, (256, 512))
+    rng = np.random.default_rng(6)
+    srcs = [t.to(DEV) for t in (_rand(rng, 2, *hw, 81), _rand(rng, 2, *hw, 128), _rand(rng, 2, *hw, 2))]
+    params = {k: torch.as_tensor(v).to(DEV) for k, v in weights.items()}
+    of = non_layers.OptFlow(params, "upflow.1.flow.", data_format="channels_last")
+    try:
+        non_layers.OptFlow.fused_sepconv = True
+        a = of.from_sources(srcs).cpu()
+        non_layers.OptFlow.fused_sepconv = False
+        b = of.from_sources(srcs).cpu()
+    finally:
+        non_layers.OptFlow.fused_sepconv = False
+    scale = float(hw[0] ** 2 + hw[1] ** 2) ** 0.5
+    torch.testing.assert_close(a / scale, b / scale, rtol=0, atol=2e-5)
