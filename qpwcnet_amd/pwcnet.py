@@ -68,11 +68,13 @@ class QpwcNet:
 
     def __init__(self, weights, train=True, input_shape=(256, 512), data_format=None,
                  use_tfa=True, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True,
-                 batch_frames=True):
+                 batch_frames=True, overlap_streams=True):
         self.data_format = image_data_format() if data_format is None else data_format
         self.axis = get_axis(self.data_format)
         self.train = train
         self.batch_frames = bool(batch_frames)
+        self.overlap_streams = bool(overlap_streams)
+        self._side = None
         self.input_shape = tuple(input_shape)
         self.device = torch.device(device)
         self.dtype = dtype
@@ -108,6 +110,8 @@ class QpwcNet:
             for l in self.enc:
                 f = l(f)
                 encs.append(f)
+            if self.overlap_streams and inputs.is_cuda:
+                return self._forward_two_streams(encs, nb)
             decs, i = [], -2
             for l in self.dec:
                 f = torch.cat([l(f), encs[i]], dim=self.axis)
@@ -121,6 +125,38 @@ class QpwcNet:
         outs = flower(self.flow, self.upflows, encs_prv[-1], encs_nxt[-1], decs_prv, decs_nxt,
                       self.data_format, output_multiscale=self.train)
         return outs if self.train else outs[0]
+
+    def _forward_two_streams(self, encs, nb):
+        """Decoder chain on a side stream, flow chain on the caller's stream: the coarse
+        levels' launches are far too small to fill 256 CUs one at a time, and the decoder
+        of level i+1 does not depend on the flow of level i (pwcnet.py:179-206 vs 39-57).
+        Level i's UpFlow waits on an event recorded after decoder i.  Captured by hipGraph
+        as two parallel branches."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=encs[-1].device)
+        side = self._side
+        side.wait_stream(main)              # encoder outputs are ready
+        decs, ready = [], []
+        with torch.cuda.stream(side):
+            f, i = encs[-1], -2
+            for l in self.dec:
+                f = torch.cat([l(f), encs[i]], dim=self.axis)
+                i -= 1
+                decs.append(f)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ready.append(ev)
+        flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
+        flos = [flo]
+        for i, upflow in enumerate(self.upflows):
+            flo_u = Upsample(scale=2.0, data_format=self.data_format)(flo)
+            main.wait_event(ready[i])
+            flo = upflow((decs[i][:nb], decs[i][nb:], flo_u))
+            flos.append(flo)
+        flos.append(Upsample(scale=2.0, data_format=self.data_format)(flo))
+        main.wait_stream(side)              # join before anything is freed or returned
+        return flos if self.train else flos[-1]
 
     @torch.no_grad()
     def predict(self, inputs):
