@@ -164,6 +164,12 @@ int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int 
  * SeparableConv2D blocks (non_layers.py:196-210, 223-231, 390-449; mish.py:27-28). */
 int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int dtype, void* stream);
 
+/* Out-of-place form that also lays down TensorFlow's 'SAME' padding for a following
+ * stride-2 3x3 convolution (0 before, pad_h / pad_w after; non_layers.py:402-409):
+ * dst (B, H+pad_h, W+pad_w, C): interior = Mish(src + bias[c]), border = 0.  src (B,H,W,C). */
+int qpwc_bias_mish_pad_fwd(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
+                           int pad_h, int pad_w, int dtype, void* stream);
+
 /* Upsample(scale) of a flow field (non_layers.py:183-193; pwcnet.py:55,60):
  * out (B,2h,2w,2) = scale * bilinear x2 upsampling (half-pixel centres, edge clamp) of
  * in (B,h,w,2), fp32 channels-last. */

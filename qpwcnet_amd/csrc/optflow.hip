@@ -418,6 +418,50 @@ __global__ __launch_bounds__(256) void bias_mish_kernel(T* __restrict__ x,
     }
 }
 
+// Out-of-place form that also produces TensorFlow's 'SAME' padding for the next stride-2
+// convolution (0 before, pad_h/pad_w after): dst is (B, H+pad_h, W+pad_w, C), its interior
+// gets Mish(src + bias) and its border zeros -- the separate F.pad copy disappears.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_mish_pad_kernel(const T* __restrict__ src,
+                                                            const float* __restrict__ bias,
+                                                            T* __restrict__ dst, int H, int W, int c4,
+                                                            int Hp, int Wp, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % c4;
+        int64_t p = i / c4;
+        const int x = p % Wp;
+        p /= Wp;
+        const int y = p % Hp;
+        const int b = p / Hp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < H && x < W) {
+            v = ld4(src + ((((int64_t)b * H + y) * W + x) * c4 + c) * 4);
+            if (bias) {
+                const float4 bv = reinterpret_cast<const float4*>(bias)[c];
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            v.x = mishf(v.x); v.y = mishf(v.y); v.z = mishf(v.z); v.w = mishf(v.w);
+        }
+        st4(dst + 4 * i, v);
+    }
+}
+
+int bias_mish_pad_launch(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
+                         int pad_h, int pad_w, int dtype, hipStream_t s) {
+    const int Hp = H + pad_h, Wp = W + pad_w;
+    const int64_t n4 = (int64_t)B * Hp * Wp * (C / 4);
+    const int64_t want = (n4 + 255) / 256;
+    const dim3 grid((unsigned)(want < 16384 ? want : 16384));
+    if (dtype == QPWC_F32)
+        hipLaunchKernelGGL(bias_mish_pad_kernel<float>, grid, dim3(256), 0, s, (const float*)src,
+                           (const float*)bias, (float*)dst, H, W, C / 4, Hp, Wp, n4);
+    else
+        hipLaunchKernelGGL(bias_mish_pad_kernel<__half>, grid, dim3(256), 0, s, (const __half*)src,
+                           (const float*)bias, (__half*)dst, H, W, C / 4, Hp, Wp, n4);
+    return check_launch("bias_mish_pad_kernel");
+}
+
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s) {
     const int64_t n4 = n_pixels * C / 4;
     const int64_t want = (n4 + 255) / 256;

@@ -189,11 +189,28 @@ class DownConv(_Weighted):
     3x3 s2 conv + Mish, 3x3 s1 conv + Mish, 3x3 s1 conv + Mish, TF 'same' padding."""
 
     def __call__(self, x):
-        y = self._nchw(x)
-        for name, stride in (("conv_a", 2), ("conv_aa", 1), ("conv_b", 1)):
-            y = conv2d_same(y, self.p(name + ".weight"), None, stride)
-            y = _bias_mish(y, self.p(name + ".bias"), self.p32(name + ".bias"), self.data_format)
-        return self._fmt(y)
+        return self.forward_padded(x)[0]
+
+    def forward_padded(self, x, padded_in=None, want_padded=False):
+        """-> (features, padded).  `padded_in`: the input already carrying the (0,1) 'SAME'
+        padding of the stride-2 conv (then `x` is ignored by conv_a).  `want_padded`: write
+        the last activation into a (B,H+1,W+1,C) buffer with a zero border, so that the NEXT
+        DownConv needs no pad copy; `features` is then the interior view of that buffer."""
+        if padded_in is not None:
+            y = F.conv2d(self._nchw(padded_in), self.p("conv_a.weight"), None, stride=2)
+        else:
+            y = conv2d_same(self._nchw(x), self.p("conv_a.weight"), None, 2)
+        y = _bias_mish(y, self.p("conv_a.bias"), self.p32("conv_a.bias"), self.data_format)
+        y = conv2d_same(y, self.p("conv_aa.weight"), None, 1)
+        y = _bias_mish(y, self.p("conv_aa.bias"), self.p32("conv_aa.bias"), self.data_format)
+        y = conv2d_same(y, self.p("conv_b.weight"), None, 1)
+        h, w = y.shape[2], y.shape[3]
+        if (want_padded and _hip_act_ok(y, self.data_format) and _same_pad(h, 3, 2) == (0, 1) and
+                _same_pad(w, 3, 2) == (0, 1)):
+            padded = ops.bias_mish_pad(y.permute(0, 2, 3, 1), self.p32("conv_b.bias"), 1, 1)
+            return padded[:, :h, :w, :], padded
+        y = _bias_mish(y, self.p("conv_b.bias"), self.p32("conv_b.bias"), self.data_format)
+        return self._fmt(y), None
 
 
 class OptFlow(_Weighted):

@@ -436,3 +436,20 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False):
                                              out.data_ptr(), B, H, W, F_, _stream(out))
     _hip.check(rc)
     return out
+
+
+def bias_mish_pad(x_nhwc, bias, pad_h, pad_w):
+    """Mish(x + bias) written into a new (B, H+pad_h, W+pad_w, C) tensor whose border is zero:
+    the activation epilogue and TensorFlow's 'SAME' padding of the following stride-2 conv
+    (non_layers.py:402-409) in one pass.  Returns the padded tensor."""
+    _check_tensor("x", x_nhwc)
+    if not x_nhwc.is_contiguous():
+        raise ValueError("bias_mish_pad needs a dense channels-last tensor")
+    B, H, W, C = x_nhwc.shape
+    out = torch.empty((B, H + pad_h, W + pad_w, C), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    with torch.cuda.device(x_nhwc.device), _timed("bias_mish_pad", (B, H, W, C)):
+        rc = _hip.lib().qpwc_bias_mish_pad_fwd(x_nhwc.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                out.data_ptr(), B, H, W, C, int(pad_h), int(pad_w),
+                                                _DTYPES[x_nhwc.dtype], _stream(x_nhwc))
+    _hip.check(rc)
+    return out

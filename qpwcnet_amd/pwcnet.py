@@ -106,9 +106,10 @@ class QpwcNet:
             # 179-206): run them once on the 2B stacked frames, then split by views.
             nb = inputs.shape[0]
             f = torch.cat([img_prv, img_nxt], dim=0)
-            encs = [f]
-            for l in self.enc:
-                f = l(f)
+            encs, padded = [f], None
+            for li, l in enumerate(self.enc):
+                # the activation epilogue of level li lays down the 'SAME' padding level li+1 needs
+                f, padded = l.forward_padded(f, padded, want_padded=li + 1 < len(self.enc))
                 encs.append(f)
             if self.overlap_streams and inputs.is_cuda:
                 return self._forward_two_streams(encs, nb)

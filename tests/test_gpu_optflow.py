@@ -195,3 +195,13 @@ def test_optflow_fused_and_unfused_sepconv_agree():
         non_layers.OptFlow.fused_sepconv = False
     scale = float(hw[0] ** 2 + hw[1] ** 2) ** 0.5
     torch.testing.assert_close(a / scale, b / scale, rtol=0, atol=2e-5)
+
+
+def test_bias_mish_pad():
+    rng = np.random.default_rng(2)
+    x = _rand(rng, 3, 10, 14, 16)
+    b = _rand(rng, 16)
+    out = ops.bias_mish_pad(x.to(DEV), b.to(DEV), 1, 1).cpu()
+    assert out.shape == (3, 11, 15, 16)
+    torch.testing.assert_close(out[:, :10, :14], torch_ref.mish(x + b), rtol=2e-6, atol=2e-6)
+    assert float(out[:, 10].abs().max()) == 0.0 and float(out[:, :, 14].abs().max()) == 0.0
