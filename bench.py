@@ -150,11 +150,15 @@ def main():
     elapsed = qdist.max_over_ranks(time.perf_counter() - t0, dev)
 
     # ---- live roofline of the dominant hot-path kernel: HIP events on the launch stream
+    # (single stream for this pass: with the decoder running beside it on the side stream the
+    # events would time the kernel while it shares the chip)
     n_prof = max(5, min(args.steps, 20))
+    model.overlap_streams = False
     with ops.kernel_timing() as kt:
         for _ in range(n_prof):
             forward()
     ktimes = kt.summary()
+    model.overlap_streams = True
     lvl4 = (B, hw[0] // 2, hw[1] // 2, synth.level_channels()[-1])
     dom_name = "warp_cost_volume" if args.fused else "cost_volume"
     dom_key = (dom_name,) + lvl4

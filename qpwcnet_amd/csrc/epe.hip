@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kEpeThreads) void epe_final_kernel(const float* __r
 // All levels of the multi-scale EPE (FlowMseLoss, qpwcnet/train/loss.py:56-67) in two
 // launches instead of 2 per level: blockIdx.y = level, blockIdx.x = partial sum.
 constexpr int kEpeMaxLevels = 8;
-constexpr int kEpeMultiBlocks = 64;
+constexpr int kEpeMultiBlocks = 256;
 struct EpeLevels {
     const float* a[kEpeMaxLevels];
     const float* b[kEpeMaxLevels];
@@ -91,11 +91,13 @@ __global__ __launch_bounds__(kEpeThreads) void epe_multi_partial_kernel(EpeLevel
     if (threadIdx.x == 0) partial[l * kEpeMultiBlocks + blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(64) void epe_multi_final_kernel(const float* __restrict__ partial,
-                                                             float* __restrict__ out, EpeLevels lv) {
+__global__ __launch_bounds__(kEpeThreads) void epe_multi_final_kernel(const float* __restrict__ partial,
+                                                                      float* __restrict__ out,
+                                                                      EpeLevels lv) {
+    __shared__ float red[kEpeThreads / 64];
     const int l = blockIdx.x;
-    float s = partial[l * kEpeMultiBlocks + threadIdx.x];  // kEpeMultiBlocks == 64 == one wave
-    s = wave_sum(s);
+    float s = (int)threadIdx.x < kEpeMultiBlocks ? partial[l * kEpeMultiBlocks + threadIdx.x] : 0.0f;
+    s = block_sum(s, red);
     if (threadIdx.x == 0) out[l] = s / (float)lv.npix[l];
 }
 
@@ -113,7 +115,7 @@ int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* 
                        lv, ws);
     int rc = check_launch("epe_multi_partial_kernel");
     if (rc != QPWC_OK) return rc;
-    hipLaunchKernelGGL(epe_multi_final_kernel, dim3(n_levels), dim3(64), 0, s, ws, out, lv);
+    hipLaunchKernelGGL(epe_multi_final_kernel, dim3(n_levels), dim3(kEpeThreads), 0, s, ws, out, lv);
     return check_launch("epe_multi_final_kernel");
 }
 

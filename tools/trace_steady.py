@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Steady-state per-kernel stats from a rocprofv3 --kernel-trace CSV of bench.py.
 MIOpen's find-mode trials during warm-up dominate the raw --stats file; this keeps only
-the forwards of the timed region (delimited by the 6 epe_final_kernel launches that end
+the forwards of the timed region (delimited by the epe_multi_final_kernel launch that ends
 every forward).  usage: trace_steady.py <kernel_trace.csv> <first_fwd> <last_fwd> <out.csv>"""
 import collections
 import csv
@@ -10,7 +10,7 @@ import sys
 path, lo, hi, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ends = [i for i, r in enumerate(rows) if "epe_final_kernel" in r["Kernel_Name"]][5::6]
+ends = [i for i, r in enumerate(rows) if "epe_multi_final_kernel" in r["Kernel_Name"]]
 a, b = ends[lo - 1] + 1, ends[hi]
 acc = collections.defaultdict(lambda: [0, 0])
 for r in rows[a:b + 1]:
