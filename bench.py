@@ -153,16 +153,32 @@ def main():
     # (single stream for this pass: with the decoder running beside it on the side stream the
     # events would time the kernel while it shares the chip)
     n_prof = max(5, min(args.steps, 20))
+    lvl4 = (B, hw[0] // 2, hw[1] // 2, synth.level_channels()[-1])
+    dom_name = "warp_cost_volume" if args.fused else "cost_volume"
+    dom_key = (dom_name,) + lvl4
     model.overlap_streams = False
-    with ops.kernel_timing() as kt:
+    with ops.kernel_timing(capture=dom_key) as kt:
         for _ in range(n_prof):
             forward()
     ktimes = kt.summary()
     model.overlap_streams = True
-    lvl4 = (B, hw[0] // 2, hw[1] // 2, synth.level_channels()[-1])
-    dom_name = "warp_cost_volume" if args.fused else "cost_volume"
-    dom_key = (dom_name,) + lvl4
-    _, dom_ms = ktimes[dom_key]
+    _, dom_ms_eager = ktimes[dom_key]
+    dom_ms = dom_ms_eager
+    if kt.captured is not None:
+        # The eager pass times event -> (host launch latency) -> kernel -> event.  For the launch
+        # DURATION rocprofv3 reports, replay the same launch on its real inputs back to back:
+        # the queue never drains, so (t1 - t0) / n is the kernel time.
+        cp, cn = kt.captured
+        n_rep = 50
+        for _ in range(5):
+            ops.cost_volume(cp, cn)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_rep):
+            ops.cost_volume(cp, cn)
+        e1.record()
+        e1.synchronize()
+        dom_ms = e0.elapsed_time(e1) / n_rep
     dom_bytes = cost_volume_bytes(*lvl4, esize)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
@@ -197,7 +213,11 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "{} L4 {}".format(dom_name, "x".join(map(str, lvl4))),
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+            "avg_launch_ms_inside_eager_step": dom_ms_eager,
             "launches_timed": ktimes[dom_key][0],
+            "method": "HIP events on the launch stream: 50 back-to-back replays of the step's own "
+                      "L4 launch (inputs captured from the forward); the eager-step figure also "
+                      "contains the host launch gap",
         },
         "hot_path": {
             "ms_per_step_eager_events": hot_ms,

@@ -21,8 +21,10 @@ class KernelTimer:
         kt.summary()  # {(op, B, H, W, C): (launches, mean_ms)}
     """
 
-    def __init__(self):
+    def __init__(self, capture=None):
         self.records = []
+        self.capture = capture    # key whose input tensors should be kept (bench: dominant kernel)
+        self.captured = None
 
     def __enter__(self):
         global _TIMER
@@ -46,8 +48,8 @@ class KernelTimer:
 _TIMER = None
 
 
-def kernel_timing():
-    return KernelTimer()
+def kernel_timing(capture=None):
+    return KernelTimer(capture)
 
 
 class _timed:
@@ -130,6 +132,8 @@ def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST, lrelu_slope
     B, H, W, C = dims
     d = 2 * int(search_range) + 1
     buf, out = _empty_like_layout(p, dims, d * d, layout, as_view)
+    if _TIMER is not None and _TIMER.capture == ("cost_volume",) + tuple(dims):
+        _TIMER.captured = (p, n)
     with torch.cuda.device(p.device), _timed("cost_volume", dims):
         rc = _hip.lib().qpwc_cost_volume_fwd(
             p.data_ptr(), n.data_ptr(), buf.data_ptr(), B, H, W, C, int(search_range), layout,

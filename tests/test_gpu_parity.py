@@ -356,3 +356,26 @@ def test_epe_multi_level():
     np.testing.assert_allclose(out, ref, rtol=1e-5)
     out2 = metrics.per_level_epe([gpu(x) for x in a], [gpu(x) for x in b]).cpu().numpy()
     np.testing.assert_allclose(out2, ref, rtol=1e-5)
+
+
+def test_randomised_shapes_every_kernel_path():
+    """Seeded random shapes through every dispatch path (vector kernel, per-wave split-K,
+    workgroup-shared, generic) against the C oracle."""
+    rng = np.random.default_rng(2026)
+    for _ in range(24):
+        B = int(rng.integers(1, 5))
+        H, W = int(rng.integers(2, 41)), int(rng.integers(2, 41))
+        C = int(rng.choice([1, 3, 4, 8, 12, 16, 32, 48, 64, 96]))
+        prv = rng.standard_normal((B, H, W, C)).astype(np.float32)
+        nxt = rng.standard_normal((B, H, W, C)).astype(np.float32)
+        flo = (rng.standard_normal((B, H, W, 2)) * 3).astype(np.float32)
+        msg = "shape {}".format((B, H, W, C))
+        np.testing.assert_allclose(ops.cost_volume(gpu(prv), gpu(nxt)).cpu().numpy(),
+                                   c_ref.cost_volume(prv, nxt), rtol=0, atol=TOL, err_msg=msg)
+        for mode in ("clamp", "tfwarp"):
+            np.testing.assert_array_equal(ops.warp(gpu(nxt), gpu(flo), mode).cpu().numpy(),
+                                          c_ref.warp(nxt, flo, mode=mode), err_msg=msg + " " + mode)
+        if C % 4 == 0:
+            fused = ops.warp_cost_volume(gpu(prv), gpu(nxt), gpu(flo)).cpu().numpy()
+            np.testing.assert_allclose(fused, c_ref.cost_volume(prv, c_ref.warp(nxt, flo)), rtol=0,
+                                       atol=TOL, err_msg=msg + " fused")
