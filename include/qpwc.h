@@ -166,9 +166,12 @@ int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int d
 
 /* Out-of-place form that also lays down TensorFlow's 'SAME' padding for a following
  * stride-2 3x3 convolution (0 before, pad_h / pad_w after; non_layers.py:402-409):
- * dst (B, H+pad_h, W+pad_w, C): interior = Mish(src + bias[c]), border = 0.  src (B,H,W,C). */
+ * dst (B, H+pad_h, W+pad_w, *): interior = Mish(src + bias[c]), border = 0.  src (B,H,W,C).
+ * dst pixels are dst_pixel_stride elements apart (>= C, multiple of 4) and `dst` already points at
+ * the first of the C destination channels: with pad 0 and a wider buffer this writes one
+ * half of the decoder's concat([up, skip]) (pwcnet.py:186-195) in place. */
 int qpwc_bias_mish_pad_fwd(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
-                           int pad_h, int pad_w, int dtype, void* stream);
+                           int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, void* stream);
 
 /* Upsample(scale) of a flow field (non_layers.py:183-193; pwcnet.py:55,60):
  * out (B,2h,2w,2) = scale * bilinear x2 upsampling (half-pixel centres, edge clamp) of

@@ -50,7 +50,7 @@ int flow_head_param_floats();
 int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, int dtype,
                            hipStream_t s);
 int bias_mish_pad_launch(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
-                         int pad_h, int pad_w, int dtype, hipStream_t s);
+                         int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
@@ -272,17 +272,22 @@ int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int d
 }
 
 int qpwc_bias_mish_pad_fwd(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
-                           int pad_h, int pad_w, int dtype, void* stream) {
+                           int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, void* stream) {
     if (!src || !dst) return fail(QPWC_E_NULL, "null pointer argument");
     if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || pad_h < 0 || pad_w < 0)
         return fail(QPWC_E_SHAPE, "bad shape B=%d H=%d W=%d C=%d pad=%d,%d", B, H, W, C, pad_h, pad_w);
+    if (dst_pixel_stride < C || dst_pixel_stride % 4)
+        return fail(QPWC_E_STRIDE, "dst_pixel_stride %lld must be >= C and a multiple of 4",
+                    (long long)dst_pixel_stride);
     const size_t es = esize(dtype);
     if ((uintptr_t)src % (4 * es) || (uintptr_t)dst % (4 * es) || (uintptr_t)bias % 16)
         return fail(QPWC_E_ALIGN, "src/dst must be aligned to 4 elements, bias to 16 bytes");
-    if (overlaps(dst, (size_t)B * (H + pad_h) * (W + pad_w) * C * es, src, (size_t)B * H * W * C * es))
+    if (overlaps(dst, (size_t)B * (H + pad_h) * (W + pad_w) * dst_pixel_stride * es, src,
+                 (size_t)B * H * W * C * es))
         return fail(QPWC_E_ALIAS, "dst overlaps src");
-    return bias_mish_pad_launch(src, bias, dst, B, H, W, C, pad_h, pad_w, dtype, (hipStream_t)stream);
+    return bias_mish_pad_launch(src, bias, dst, B, H, W, C, pad_h, pad_w, dst_pixel_stride, dtype,
+                                (hipStream_t)stream);
 }
 
 int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, int dtype,

@@ -40,7 +40,6 @@ struct DwSrc {
     int64_t stride[3];  // floats per pixel of each source
 };
 
-constexpr int kDwRows = 8;  // rows per thread strip
 constexpr int kDwPx = 4;    // consecutive pixels per thread
 
 // thread = (4 consecutive pixels, 1 channel): per input row it loads 6 values, applies
@@ -50,14 +49,14 @@ constexpr int kDwPx = 4;    // consecutive pixels per thread
 template <typename T, bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* __restrict__ weight,
                                                         T* __restrict__ out, int H, int W, int C,
-                                                        int strips, int wq) {
+                                                        int strips, int wq, int rows) {
     const int64_t rowthreads = (int64_t)wq * C;  // (x-quad, channel) pairs of one row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rowthreads) return;
     const int xq = (int)(idx / C), c = (int)(idx - (int64_t)xq * C);
     const int x0 = xq * kDwPx;
     const int strip = blockIdx.y % strips, b = blockIdx.y / strips;
-    const int y0 = strip * kDwRows;
+    const int y0 = strip * rows;
 
     // which source holds channel c
     const T* p;
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
     activate(y0, r1);
     T* o = out + ((int64_t)(b * H + y0) * W + x0) * C + c;
     const int64_t rowlen = (int64_t)W * C;
-    const int yend = y0 + kDwRows < H ? y0 + kDwRows : H;
+    const int yend = y0 + rows < H ? y0 + rows : H;
     for (int y = y0; y < yend; ++y) {
 #pragma unroll
         for (int j = 0; j < kDwPx + 2; ++j) r2[j] = ahead[j];
@@ -131,13 +130,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
 
 template <typename T>
 static void dwconv_dispatch(const DwSrc& d, int act, const void* weight, void* out, int H, int W, int C,
-                            int strips, int wq, dim3 grid, hipStream_t s) {
+                            int strips, int wq, int rows, dim3 grid, hipStream_t s) {
     if (act)
         hipLaunchKernelGGL((dwconv3x3_kernel<T, true>), grid, dim3(256), 0, s, d, (const float*)weight,
-                           (T*)out, H, W, C, strips, wq);
+                           (T*)out, H, W, C, strips, wq, rows);
     else
         hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), grid, dim3(256), 0, s, d, (const float*)weight,
-                           (T*)out, H, W, C, strips, wq);
+                           (T*)out, H, W, C, strips, wq, rows);
 }
 
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
@@ -151,14 +150,17 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
         d.stride[i] = i < n_src ? strides[i] : 0;
         C += d.ch[i];
     }
-    const int strips = (H + kDwRows - 1) / kDwRows;
+    // rows per thread strip: long strips amortise the 2 halo rows on big images, short ones
+    // give small (coarse-level) images enough threads and a short dependent-load chain
+    const int rows = H >= 64 ? 8 : (H >= 32 ? 4 : 2);
+    const int strips = (H + rows - 1) / rows;
     const int wq = (W + kDwPx - 1) / kDwPx;
     const int64_t rowthreads = (int64_t)wq * C;
     const dim3 grid((unsigned)((rowthreads + 255) / 256), (unsigned)(strips * B));
     if (dtype == QPWC_F32)
-        dwconv_dispatch<float>(d, act, weight, out, H, W, C, strips, wq, grid, s);
+        dwconv_dispatch<float>(d, act, weight, out, H, W, C, strips, wq, rows, grid, s);
     else
-        dwconv_dispatch<__half>(d, act, weight, out, H, W, C, strips, wq, grid, s);
+        dwconv_dispatch<__half>(d, act, weight, out, H, W, C, strips, wq, rows, grid, s);
     return check_launch("dwconv3x3_kernel");
 }
 
@@ -425,7 +427,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bias_mish_pad_kernel(const T* __restrict__ src,
                                                             const float* __restrict__ bias,
                                                             T* __restrict__ dst, int H, int W, int c4,
-                                                            int Hp, int Wp, int64_t n4) {
+                                                            int Hp, int Wp, int64_t n4, int64_t dps) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int c = i % c4;
@@ -443,22 +445,22 @@ __global__ __launch_bounds__(256) void bias_mish_pad_kernel(const T* __restrict_
             }
             v.x = mishf(v.x); v.y = mishf(v.y); v.z = mishf(v.z); v.w = mishf(v.w);
         }
-        st4(dst + 4 * i, v);
+        st4(dst + (i / c4) * dps + 4 * c, v);
     }
 }
 
 int bias_mish_pad_launch(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
-                         int pad_h, int pad_w, int dtype, hipStream_t s) {
+                         int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, hipStream_t s) {
     const int Hp = H + pad_h, Wp = W + pad_w;
     const int64_t n4 = (int64_t)B * Hp * Wp * (C / 4);
     const int64_t want = (n4 + 255) / 256;
     const dim3 grid((unsigned)(want < 16384 ? want : 16384));
     if (dtype == QPWC_F32)
         hipLaunchKernelGGL(bias_mish_pad_kernel<float>, grid, dim3(256), 0, s, (const float*)src,
-                           (const float*)bias, (float*)dst, H, W, C / 4, Hp, Wp, n4);
+                           (const float*)bias, (float*)dst, H, W, C / 4, Hp, Wp, n4, dst_pixel_stride);
     else
         hipLaunchKernelGGL(bias_mish_pad_kernel<__half>, grid, dim3(256), 0, s, (const __half*)src,
-                           (const float*)bias, (__half*)dst, H, W, C / 4, Hp, Wp, n4);
+                           (const float*)bias, (__half*)dst, H, W, C / 4, Hp, Wp, n4, dst_pixel_stride);
     return check_launch("bias_mish_pad_kernel");
 }
 

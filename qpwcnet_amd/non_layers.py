@@ -183,6 +183,19 @@ class UpConv(_Weighted):
         y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), None, stride=2, padding=1)
         return self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.p32("conv_up.bias"), self.data_format))
 
+    def cat_skip(self, x, skip):
+        """concat([UpConv(x), skip]) on the channel axis (pwcnet.py:186-195).  On the HIP path the
+        activation epilogue writes its half straight into the concat buffer."""
+        y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), None, stride=2, padding=1)
+        if _hip_act_ok(y, self.data_format) and skip.shape[3] % 4 == 0:
+            c1, c2 = y.shape[1], skip.shape[3]
+            buf = torch.empty(skip.shape[:3] + (c1 + c2,), dtype=y.dtype, device=y.device)
+            ops.bias_mish_into(y.permute(0, 2, 3, 1), self.p32("conv_up.bias"), buf, 0)
+            buf[..., c1:] = skip
+            return buf
+        up = self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.p32("conv_up.bias"), self.data_format))
+        return torch.cat([up, skip], dim=self.axis)
+
 
 class DownConv(_Weighted):
     """qpwcnet/core/non_layers.py:390-449 with use_normalizer=False (pwcnet.py:146):

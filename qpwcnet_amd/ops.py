@@ -453,7 +453,27 @@ def bias_mish_pad(x_nhwc, bias, pad_h, pad_w):
     out = torch.empty((B, H + pad_h, W + pad_w, C), dtype=x_nhwc.dtype, device=x_nhwc.device)
     with torch.cuda.device(x_nhwc.device), _timed("bias_mish_pad", (B, H, W, C)):
         rc = _hip.lib().qpwc_bias_mish_pad_fwd(x_nhwc.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                                                out.data_ptr(), B, H, W, C, int(pad_h), int(pad_w),
+                                                out.data_ptr(), B, H, W, C, int(pad_h), int(pad_w), C,
                                                 _DTYPES[x_nhwc.dtype], _stream(x_nhwc))
     _hip.check(rc)
     return out
+
+
+def bias_mish_into(x_nhwc, bias, dst, channel_offset=0):
+    """Mish(x + bias) written into channels [offset, offset+C) of the wider dense channels-last
+    buffer `dst` (B,H,W,Ctot): one half of the decoder's concat([up, skip]) (pwcnet.py:186-195)
+    without the concat copy of that half.  Returns dst."""
+    _check_tensor("x", x_nhwc)
+    _check_tensor("dst", dst)
+    if not (x_nhwc.is_contiguous() and dst.is_contiguous()) or dst.dtype != x_nhwc.dtype:
+        raise ValueError("bias_mish_into needs dense channels-last tensors of one dtype")
+    B, H, W, C = x_nhwc.shape
+    if tuple(dst.shape[:3]) != (B, H, W) or channel_offset % 4 or channel_offset + C > dst.shape[3]:
+        raise ValueError("dst must be (B,H,W,Ctot) with room for C channels at a 4-aligned offset")
+    es = dst.element_size()
+    with torch.cuda.device(dst.device), _timed("bias_mish_into", (B, H, W, C)):
+        rc = _hip.lib().qpwc_bias_mish_pad_fwd(x_nhwc.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                dst.data_ptr() + channel_offset * es, B, H, W, C, 0, 0,
+                                                dst.shape[3], _DTYPES[dst.dtype], _stream(dst))
+    _hip.check(rc)
+    return dst

@@ -115,7 +115,7 @@ class QpwcNet:
                 return self._forward_two_streams(encs, nb)
             decs, i = [], -2
             for l in self.dec:
-                f = torch.cat([l(f), encs[i]], dim=self.axis)
+                f = l.cat_skip(f, encs[i])
                 i -= 1
                 decs.append(f)
             encs_prv, encs_nxt = [e[:nb] for e in encs], [e[nb:] for e in encs]
@@ -142,7 +142,7 @@ class QpwcNet:
         with torch.cuda.stream(side):
             f, i = encs[-1], -2
             for l in self.dec:
-                f = torch.cat([l(f), encs[i]], dim=self.axis)
+                f = l.cat_skip(f, encs[i])
                 i -= 1
                 decs.append(f)
                 ev = torch.cuda.Event()

@@ -205,3 +205,14 @@ def test_bias_mish_pad():
     assert out.shape == (3, 11, 15, 16)
     torch.testing.assert_close(out[:, :10, :14], torch_ref.mish(x + b), rtol=2e-6, atol=2e-6)
     assert float(out[:, 10].abs().max()) == 0.0 and float(out[:, :, 14].abs().max()) == 0.0
+
+
+def test_bias_mish_into_concat_buffer():
+    rng = np.random.default_rng(4)
+    x, b = _rand(rng, 2, 6, 10, 16), _rand(rng, 16)
+    dst = torch.full((2, 6, 10, 40), 7.0, device=DEV)
+    ops.bias_mish_into(x.to(DEV), b.to(DEV), dst, 8)
+    torch.testing.assert_close(dst[..., 8:24].cpu(), torch_ref.mish(x + b), rtol=2e-6, atol=2e-6)
+    assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 24:] == 7.0).all())
+    with pytest.raises(ValueError):
+        ops.bias_mish_into(x.to(DEV), b.to(DEV), dst, 30)
