@@ -173,6 +173,13 @@ int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int d
 int qpwc_bias_mish_pad_fwd(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
                            int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, void* stream);
 
+/* Split(2) of the (B,H,W,6) input pair (pwcnet.py:229), the two frames stacked on the batch
+ * axis (frame f of pair b at f*B + b; the encoder weights are shared, pwcnet.py:145-162) and
+ * zero-padded by pad_h/pad_w at the far edges ('SAME' padding of the first stride-2 conv):
+ * out (2B, H+pad_h, W+pad_w, 3). */
+int qpwc_split_frames_pad_fwd(const void* in, void* out, int B, int H, int W, int pad_h, int pad_w,
+                              int dtype, void* stream);
+
 /* Upsample(scale) of a flow field (non_layers.py:183-193; pwcnet.py:55,60):
  * out (B,2h,2w,2) = scale * bilinear x2 upsampling (half-pixel centres, edge clamp) of
  * in (B,h,w,2), fp32 channels-last. */

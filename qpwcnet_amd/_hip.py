@@ -26,7 +26,7 @@ SYMBOLS = (
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_bias_mish_fwd",
     "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd",
-    "qpwc_sepconv3x3_fwd", "qpwc_bias_mish_pad_fwd",
+    "qpwc_sepconv3x3_fwd", "qpwc_bias_mish_pad_fwd", "qpwc_split_frames_pad_fwd",
 )
 
 _lib = None
@@ -99,6 +99,8 @@ def lib():
     L.qpwc_sepconv3x3_fwd.restype = ci
     L.qpwc_bias_mish_pad_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, vp]
     L.qpwc_bias_mish_pad_fwd.restype = ci
+    L.qpwc_split_frames_pad_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    L.qpwc_split_frames_pad_fwd.restype = ci
     _lib = L
     return L
 

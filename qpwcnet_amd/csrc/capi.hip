@@ -51,6 +51,8 @@ int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float
                            hipStream_t s);
 int bias_mish_pad_launch(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
                          int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, hipStream_t s);
+int split_frames_pad_launch(const void* in, void* out, int B, int H, int W, int pad_h, int pad_w, int dtype,
+                            hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
@@ -288,6 +290,19 @@ int qpwc_bias_mish_pad_fwd(const void* src, const void* bias, void* dst, int B, 
         return fail(QPWC_E_ALIAS, "dst overlaps src");
     return bias_mish_pad_launch(src, bias, dst, B, H, W, C, pad_h, pad_w, dst_pixel_stride, dtype,
                                 (hipStream_t)stream);
+}
+
+int qpwc_split_frames_pad_fwd(const void* in, void* out, int B, int H, int W, int pad_h, int pad_w,
+                              int dtype, void* stream) {
+    if (!in || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
+    if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0)
+        return fail(QPWC_E_SHAPE, "bad shape B=%d H=%d W=%d pad=%d,%d", B, H, W, pad_h, pad_w);
+    const size_t es = esize(dtype);
+    if ((uintptr_t)in % es || (uintptr_t)out % es) return fail(QPWC_E_ALIGN, "pointer not element aligned");
+    if (overlaps(out, (size_t)2 * B * (H + pad_h) * (W + pad_w) * 3 * es, in, (size_t)B * H * W * 6 * es))
+        return fail(QPWC_E_ALIAS, "out overlaps in");
+    return split_frames_pad_launch(in, out, B, H, W, pad_h, pad_w, dtype, (hipStream_t)stream);
 }
 
 int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, int dtype,

@@ -524,6 +524,44 @@ int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float
     return check_launch("upsample2x_flow_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// Split(2) of the (B,H,W,6) input pair (pwcnet.py:229) + stacking of the two frames on the
+// batch axis (the encoder weights are shared) + the 'SAME' padding of the first stride-2
+// conv, in one pass: out (2B, H+pad_h, W+pad_w, 3), frame f of pair b at batch f*B + b.
+template <typename T>
+__global__ __launch_bounds__(256) void split_frames_pad_kernel(const T* __restrict__ in,
+                                                               T* __restrict__ out, int B, int H, int W,
+                                                               int Hp, int Wp, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = idx % 3;
+        int64_t p = idx / 3;
+        const int x = p % Wp;
+        p /= Wp;
+        const int y = p % Hp;
+        const int b2 = p / Hp;
+        const int f = b2 / B, b = b2 - f * B;
+        float v = 0.0f;
+        if (y < H && x < W) v = ld(in + (((int64_t)b * H + y) * W + x) * 6 + f * 3 + c);
+        st(out + idx, v);
+    }
+}
+
+int split_frames_pad_launch(const void* in, void* out, int B, int H, int W, int pad_h, int pad_w, int dtype,
+                            hipStream_t s) {
+    const int Hp = H + pad_h, Wp = W + pad_w;
+    const int64_t total = (int64_t)2 * B * Hp * Wp * 3;
+    const int64_t want = (total + 255) / 256;
+    const dim3 grid((unsigned)(want < 32768 ? want : 32768));
+    if (dtype == QPWC_F32)
+        hipLaunchKernelGGL(split_frames_pad_kernel<float>, grid, dim3(256), 0, s, (const float*)in,
+                           (float*)out, B, H, W, Hp, Wp, total);
+    else
+        hipLaunchKernelGGL(split_frames_pad_kernel<__half>, grid, dim3(256), 0, s, (const __half*)in,
+                           (__half*)out, B, H, W, Hp, Wp, total);
+    return check_launch("split_frames_pad_kernel");
+}
+
 int flow_head_param_floats() { return kFhParams; }
 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,

@@ -477,3 +477,19 @@ def bias_mish_into(x_nhwc, bias, dst, channel_offset=0):
                                                 dst.shape[3], _DTYPES[dst.dtype], _stream(dst))
     _hip.check(rc)
     return dst
+
+
+def split_frames_pad(pairs, pad_h=0, pad_w=0):
+    """(B,H,W,6) channels-last input pair -> (2B, H+pad_h, W+pad_w, 3): Split(2) (pwcnet.py:229),
+    both frames stacked on the batch axis, far edges zero-padded for the first stride-2 conv."""
+    _check_tensor("pairs", pairs)
+    if pairs.shape[3] != 6:
+        raise ValueError("pairs must be (B,H,W,6)")
+    x = pairs.contiguous()
+    B, H, W, _ = x.shape
+    out = torch.empty((2 * B, H + pad_h, W + pad_w, 3), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device), _timed("split_frames_pad", (B, H, W, 6)):
+        rc = _hip.lib().qpwc_split_frames_pad_fwd(x.data_ptr(), out.data_ptr(), B, H, W, int(pad_h),
+                                                   int(pad_w), _DTYPES[x.dtype], _stream(x))
+    _hip.check(rc)
+    return out

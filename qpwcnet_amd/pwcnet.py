@@ -7,6 +7,7 @@ kernels; everything else is PyTorch-ROCm (MIOpen / hipBLASLt).  Inference only.
 import numpy as np
 import torch
 
+from . import ops
 from .backend import CHANNELS_FIRST, CHANNELS_LAST, get_axis, image_data_format
 from .non_layers import DownConv, Flow, Split, UpConv, UpFlow, Upsample
 from .synth import DEC_FILTERS, ENC_FILTERS, make_weights
@@ -105,8 +106,15 @@ class QpwcNet:
             # The encoder/decoder weights are shared by both frames (pwcnet.py:145-162,
             # 179-206): run them once on the 2B stacked frames, then split by views.
             nb = inputs.shape[0]
-            f = torch.cat([img_prv, img_nxt], dim=0)
-            encs, padded = [f], None
+            h, w = self.input_shape
+            if (self.data_format == CHANNELS_LAST and inputs.is_cuda and h % 2 == 0 and w % 2 == 0 and
+                    inputs.dtype in (torch.float32, torch.float16)):
+                # split + stack + 'SAME' padding of the first stride-2 conv in one pass
+                padded = ops.split_frames_pad(inputs, 1, 1)
+                f = padded[:, :h, :w, :]
+            else:
+                f, padded = torch.cat([img_prv, img_nxt], dim=0), None
+            encs = [f]
             for li, l in enumerate(self.enc):
                 # the activation epilogue of level li lays down the 'SAME' padding level li+1 needs
                 f, padded = l.forward_padded(f, padded, want_padded=li + 1 < len(self.enc))

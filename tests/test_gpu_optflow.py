@@ -216,3 +216,13 @@ def test_bias_mish_into_concat_buffer():
     assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 24:] == 7.0).all())
     with pytest.raises(ValueError):
         ops.bias_mish_into(x.to(DEV), b.to(DEV), dst, 30)
+
+
+def test_split_frames_pad():
+    rng = np.random.default_rng(8)
+    x = _rand(rng, 3, 10, 12, 6)
+    out = ops.split_frames_pad(x.to(DEV), 1, 1).cpu()
+    assert out.shape == (6, 11, 13, 3)
+    assert torch.equal(out[:3, :10, :12], x[..., :3]) and torch.equal(out[3:, :10, :12], x[..., 3:])
+    assert float(out[:, 10].abs().max()) == 0.0 and float(out[:, :, 12].abs().max()) == 0.0
+    assert torch.equal(ops.split_frames_pad(x.to(DEV)).cpu(), torch.cat([x[..., :3], x[..., 3:]], dim=0))
