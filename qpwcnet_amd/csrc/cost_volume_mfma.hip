@@ -642,6 +642,12 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
                             int dtype, int64_t ops, float slope, hipStream_t s) {
     if (C % 16 != 0 || (reinterpret_cast<uintptr_t>(prv) | reinterpret_cast<uintptr_t>(nxt)) % 16)
         return 1;
+    // 32-bit byte offsets inside one image (buffer descriptors) and 32-bit element offsets
+    // inside one output image: larger problems take the 64-bit vector kernel instead
+    const int64_t es = dtype == QPWC_F16 ? 2 : 4;
+    if ((int64_t)(H + 8) * (W + 8) * C * es >= 0x7fffffff || (int64_t)H * W * ops > INT32_MAX ||
+        (int64_t)((W + 3) / 4) * ((H + 3) / 4) * B > INT32_MAX)
+        return 1;
     if (dtype == QPWC_F32) {
         // many tiles: share the staged neighbourhood across a workgroup
         if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 1024 && lds_mode() != 0)
