@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 from qpwcnet_amd import dist as qdist  # noqa: E402
 from qpwcnet_amd import metrics, ops, synth  # noqa: E402
-from qpwcnet_amd.pwcnet import build_flower  # noqa: E402
+from qpwcnet_amd.pwcnet import GraphedForward, build_flower  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s copy-measured
 
@@ -118,14 +118,8 @@ def main():
 
     graph = None
     if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            flows, epe_local = forward()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            flows, epe_local = forward()
+        graph = GraphedForward(model, pairs, epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=0)
+        flows, epe_local = graph.outputs, graph.extra
 
     def step():
         if graph is not None:

@@ -261,39 +261,18 @@ def epe(y_true, y_pred, data_format=CHANNELS_LAST):
 
 def dwconv3x3(sources, weight, mish_on_load=False):
     """Depthwise 3x3 'same' convolution over the channel-wise concatenation of 1..3
-    channels-last fp32/fp16 sources (each (B,H,W,Ci), last dim contiguous; fp32 weights) -- the depthwise
-    half of OptFlow's SeparableConv2D (qpwcnet/core/non_layers.py:223-231) without ever
+    channels-last fp32/fp16 sources (each (B,H,W,Ci), last dim contiguous; fp32 weights) -- the
+    depthwise half of OptFlow's SeparableConv2D (qpwcnet/core/non_layers.py:223-231) without ever
     building Flow/UpFlow's concat (non_layers.py:336-338, 381-385).
     weight: (C,1,3,3) or (C,3,3) with C = sum(Ci).  -> (B,H,W,C)."""
-    import ctypes
-    if not 1 <= len(sources) <= 3:
-        raise ValueError("dwconv3x3 takes 1..3 sources")
-    B, H, W = sources[0].shape[:3]
-    chans, strides, ptrs, keep = [], [], [], []
-    for i, t in enumerate(sources):
-        _check_tensor("source %d" % i, t)
-        if t.dtype != sources[0].dtype:
-            raise ValueError("dwconv3x3 sources must share one dtype")
-        if tuple(t.shape[:3]) != (B, H, W):
-            raise ValueError("sources must share B,H,W")
-        if t.stride(3) != 1 or t.stride(1) != W * t.stride(2) or t.stride(0) != H * t.stride(1):
-            t = t.contiguous()
-        keep.append(t)
-        chans.append(t.shape[3])
-        strides.append(t.stride(2))
-        ptrs.append(t.data_ptr())
-    C = sum(chans)
+    keep, c_ptrs, c_ch, c_st, B, H, W, C = _dw_sources(sources)
     w = weight.reshape(-1, 9)
     if w.shape[0] != C or w.dtype != torch.float32 or not w.is_cuda:
         raise ValueError("weight must be fp32 (C,3,3) on the device with C = {}".format(C))
     w = w.contiguous()
     out = torch.empty((B, H, W, C), dtype=keep[0].dtype, device=keep[0].device)
-    n = len(keep)
-    c_ptrs = (ctypes.c_void_p * n)(*ptrs)
-    c_ch = (ctypes.c_int * n)(*chans)
-    c_st = (ctypes.c_int64 * n)(*strides)
     with torch.cuda.device(out.device), _timed("dwconv3x3", (B, H, W, C)):
-        rc = _hip.lib().qpwc_dwconv3x3_fwd(c_ptrs, c_ch, c_st, n, int(bool(mish_on_load)),
+        rc = _hip.lib().qpwc_dwconv3x3_fwd(c_ptrs, c_ch, c_st, len(keep), int(bool(mish_on_load)),
                                             w.data_ptr(), out.data_ptr(), B, H, W, _DTYPES[out.dtype],
                                             _stream(out))
     _hip.check(rc)
@@ -389,7 +368,7 @@ def _dw_sources(sources):
     """-> (kept tensors, ctypes pointer/channel/stride arrays, B, H, W, C) for 1..3 sources."""
     import ctypes
     if not 1 <= len(sources) <= 3:
-        raise ValueError("1..3 sources")
+        raise ValueError("takes 1..3 sources")
     B, H, W = sources[0].shape[:3]
     chans, strides, ptrs, keep = [], [], [], []
     for i, t in enumerate(sources):

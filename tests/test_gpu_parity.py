@@ -379,3 +379,30 @@ def test_randomised_shapes_every_kernel_path():
             fused = ops.warp_cost_volume(gpu(prv), gpu(nxt), gpu(flo)).cpu().numpy()
             np.testing.assert_allclose(fused, c_ref.cost_volume(prv, c_ref.warp(nxt, flo)), rtol=0,
                                        atol=TOL, err_msg=msg + " fused")
+
+
+def test_graphed_forward_replays_match_eager():
+    from qpwcnet_amd.pwcnet import GraphedForward
+    hw = (64, 128)
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(2, hw[0], hw[1], seed=1)
+    pairs2, _ = synth.make_frames(2, hw[0], hw[1], seed=2)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV)
+    g = GraphedForward(model, gpu(pairs))
+    for p in (pairs2, pairs):
+        outs, _ = g.replay(gpu(p))
+        eager = model.predict(p)
+        for a, b in zip(outs, eager):
+            assert torch.allclose(a, b, rtol=0, atol=1e-5)
+
+
+def test_config4_full_network_one_pair_1024x2048():
+    """BASELINE configs[3] resolution, one pair: per-level EPE vs the CPU oracle."""
+    hw = (1024, 2048)
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(1, hw[0], hw[1], seed=3)
+    flows = build_flower(True, hw, "channels_last", weights=weights, device=DEV).predict(pairs)
+    ref = net_ref.RefNet(weights)(pairs)
+    for lvl, (a, b) in enumerate(zip(flows, ref)):
+        e = float(torch_ref.epe_error(a.cpu(), b))
+        assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
