@@ -232,10 +232,15 @@ class OptFlow(_Weighted):
     times sqrt(h^2 + w^2) of the input's spatial size."""
 
     BN_EPS = 1e-3
-    # class-wide switch: fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd) instead of
-    # dwconv + library GEMM.  Measured slower at every level so far (25 TF vs 75 TF for the
-    # GEMM half), so it is off by default and kept for the tests / later tuning.
+    # Fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd) instead of dwconv + library GEMM:
+    # False / True = never / always, None = per layer by size (_fuse_layer).  Measured inside the
+    # captured step: never 1.87 ms, by-size 1.90 ms, always 2.30 ms -- the kernel reaches 25 TF
+    # against the library GEMM's 75-90 TF, so it stays off; kept (and tested) for later tuning.
     fused_sepconv = False
+
+    @staticmethod
+    def _fuse_layer(c_in, n_pixels):
+        return c_in <= 64 or (c_in <= 128 and n_pixels <= 16384)
 
     def __init__(self, params, prefix, filters=(128, 64, 32, 16), scale=None, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
@@ -274,9 +279,12 @@ class OptFlow(_Weighted):
         B, H, W = sources[0].shape[:3]
         scale = self.scale if self.scale is not None else float(H ** 2 + W ** 2) ** 0.5
         z = None
-        fused = self.fused_sepconv and sources[0].dtype == torch.float32
+        fp32 = sources[0].dtype == torch.float32
         for i in range(len(self.filters)):
             src = sources if i == 0 else [z]
+            c_in = self._dw[i].shape[0]
+            fused = fp32 and (self._fuse_layer(c_in, B * H * W) if self.fused_sepconv is None
+                              else bool(self.fused_sepconv))
             if fused:  # depthwise + pointwise + bias in one launch, depthwise result stays on chip
                 z = ops.sepconv3x3(src, self._dw[i], self._pw_pad[i], self._pw_b32[i], mish_on_load=i > 0)
             else:
