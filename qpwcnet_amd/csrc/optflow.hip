@@ -128,6 +128,122 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
     }
 }
 
+// Single-source, aligned case (every SeparableConv after the first): a lane owns VEC
+// consecutive channels, so loads and stores are VEC elements wide (fp16 with one channel per
+// lane moves only 128 B per wave instruction).  Same 4-pixel x row-strip scheme.
+template <typename T, int VEC>
+struct VecIo;
+template <>
+struct VecIo<__half, 4> {
+    static __device__ __forceinline__ void load(const __half* p, float (&v)[4]) {
+        const float4 t = ld4(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(__half* p, const float (&v)[4]) {
+        st4(p, make_float4(v[0], v[1], v[2], v[3]));
+    }
+};
+
+template <typename T, int VEC, bool ACT>
+__global__ __launch_bounds__(256) void dwconv3x3_vec_kernel(const T* __restrict__ in, int64_t ps,
+                                                            const float* __restrict__ weight,
+                                                            T* __restrict__ out, int H, int W, int C,
+                                                            int strips, int wq, int rows) {
+    const int cv = C / VEC;
+    const int64_t rowthreads = (int64_t)wq * cv;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rowthreads) return;
+    const int xq = (int)(idx / cv), c = (int)(idx - (int64_t)xq * cv) * VEC;
+    const int x0 = xq * kDwPx;
+    const int strip = blockIdx.y % strips, b = blockIdx.y / strips;
+    const int y0 = strip * rows;
+    const T* p = in + (int64_t)b * H * W * ps + c;
+
+    float w[9][VEC];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[k][e] = weight[(c + e) * 9 + k];
+
+    bool col_ok[kDwPx + 2];
+#pragma unroll
+    for (int j = 0; j < kDwPx + 2; ++j) col_ok[j] = x0 - 1 + j >= 0 && x0 - 1 + j < W;
+
+    auto load_row = [&](int y, float (&r)[kDwPx + 2][VEC]) {
+        const bool row_ok = y >= 0 && y < H;
+        const T* q = p + ((int64_t)y * W + (x0 - 1)) * ps;
+#pragma unroll
+        for (int j = 0; j < kDwPx + 2; ++j) {
+            if (row_ok && col_ok[j]) {
+                VecIo<T, VEC>::load(q + (int64_t)j * ps, r[j]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r[j][e] = 0.0f;
+            }
+        }
+    };
+    auto activate = [&](int y, float (&r)[kDwPx + 2][VEC]) {
+        if (!ACT) return;
+        const bool row_ok = y >= 0 && y < H;
+#pragma unroll
+        for (int j = 0; j < kDwPx + 2; ++j)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[j][e] = (row_ok && col_ok[j]) ? mishf(r[j][e]) : 0.0f;
+    };
+
+    float r0[kDwPx + 2][VEC], r1[kDwPx + 2][VEC], r2[kDwPx + 2][VEC];
+    load_row(y0 - 1, r0);
+    load_row(y0, r1);
+    activate(y0 - 1, r0);
+    activate(y0, r1);
+    T* o = out + ((int64_t)(b * H + y0) * W + x0) * C + c;
+    const int64_t rowlen = (int64_t)W * C;
+    const int yend = y0 + rows < H ? y0 + rows : H;
+    for (int y = y0; y < yend; ++y) {
+        load_row(y + 1, r2);
+        activate(y + 1, r2);
+#pragma unroll
+        for (int i = 0; i < kDwPx; ++i) {
+            float a[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float s = w[0][e] * r0[i][e];
+                s = fmaf(w[1][e], r0[i + 1][e], s);
+                s = fmaf(w[2][e], r0[i + 2][e], s);
+                s = fmaf(w[3][e], r1[i][e], s);
+                s = fmaf(w[4][e], r1[i + 1][e], s);
+                s = fmaf(w[5][e], r1[i + 2][e], s);
+                s = fmaf(w[6][e], r2[i][e], s);
+                s = fmaf(w[7][e], r2[i + 1][e], s);
+                s = fmaf(w[8][e], r2[i + 2][e], s);
+                a[e] = s;
+            }
+            if (x0 + i < W) VecIo<T, VEC>::store(o + (int64_t)i * C, a);
+        }
+        o += rowlen;
+#pragma unroll
+        for (int j = 0; j < kDwPx + 2; ++j)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                r0[j][e] = r1[j][e];
+                r1[j][e] = r2[j][e];
+            }
+    }
+}
+
+template <typename T, int VEC>
+static void dwconv_vec_dispatch(const DwSrc& d, int act, const void* weight, void* out, int B, int H, int W,
+                                int C, int strips, int wq, int rows, hipStream_t s) {
+    const int64_t rowthreads = (int64_t)wq * (C / VEC);
+    const dim3 grid((unsigned)((rowthreads + 255) / 256), (unsigned)(strips * B));
+    if (act)
+        hipLaunchKernelGGL((dwconv3x3_vec_kernel<T, VEC, true>), grid, dim3(256), 0, s, (const T*)d.ptr[0],
+                           d.stride[0], (const float*)weight, (T*)out, H, W, C, strips, wq, rows);
+    else
+        hipLaunchKernelGGL((dwconv3x3_vec_kernel<T, VEC, false>), grid, dim3(256), 0, s, (const T*)d.ptr[0],
+                           d.stride[0], (const float*)weight, (T*)out, H, W, C, strips, wq, rows);
+}
+
 template <typename T>
 static void dwconv_dispatch(const DwSrc& d, int act, const void* weight, void* out, int H, int W, int C,
                             int strips, int wq, int rows, dim3 grid, hipStream_t s) {
@@ -155,6 +271,15 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
     const int rows = H >= 64 ? 8 : (H >= 32 ? 4 : 2);
     const int strips = (H + rows - 1) / rows;
     const int wq = (W + kDwPx - 1) / kDwPx;
+    // fp16 storage, single aligned source: 4 channels per lane (measured +3 % on the fp16 step;
+    // the fp32 analogue with 2 channels per lane measured 1.5 % slower than one per lane)
+    const bool vec_ok = dtype == QPWC_F16 && n_src == 1 && d.stride[0] % 4 == 0 && C % 4 == 0 &&
+                        reinterpret_cast<uintptr_t>(d.ptr[0]) % 8 == 0 &&
+                        reinterpret_cast<uintptr_t>(out) % 8 == 0;
+    if (vec_ok) {
+        dwconv_vec_dispatch<__half, 4>(d, act, weight, out, B, H, W, C, strips, wq, rows, s);
+        return check_launch("dwconv3x3_vec_kernel");
+    }
     const int64_t rowthreads = (int64_t)wq * C;
     const dim3 grid((unsigned)((rowthreads + 255) / 256), (unsigned)(strips * B));
     if (dtype == QPWC_F32)
