@@ -51,7 +51,8 @@ __device__ __forceinline__ void store_tile(const float* fr, T* ob, int lane, int
                                            int W, int out_pix_stride, float slope, float inv_c,
                                            float cf) {
     const int row_stride = W * out_pix_stride;
-    if (out_pix_stride == 81 && (W & 3) == 0 && x0 + 4 <= W && y0 + 4 <= H) {  // wave-uniform
+    if (out_pix_stride == 81 && (W & 3) == 0 && x0 + 4 <= W && y0 + 4 <= H &&
+        (reinterpret_cast<uintptr_t>(ob) & (4 * sizeof(T) - 1)) == 0) {  // wave-uniform
         // lane owns elements 4*q .. 4*q+3 of the 324-float row, q = lane (+64 for lanes 0..16)
         int foff[2][4];
 #pragma unroll

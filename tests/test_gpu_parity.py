@@ -406,3 +406,21 @@ def test_config4_full_network_one_pair_1024x2048():
     for lvl, (a, b) in enumerate(zip(flows, ref)):
         e = float(torch_ref.epe_error(a.cpu(), b))
         assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
+
+
+def test_cost_volume_output_only_element_aligned():
+    """The C ABI asks for element alignment only: an output that is 4-byte but not 16-byte
+    aligned must take the scalar-store path of the tile epilogue."""
+    from qpwcnet_amd import _hip
+    rng = np.random.default_rng(13)
+    shape = (16, 64, 64, 32)
+    prv = rng.standard_normal(shape).astype(np.float32)
+    nxt = rng.standard_normal(shape).astype(np.float32)
+    p, n = gpu(prv), gpu(nxt)
+    buf = torch.zeros(16 * 64 * 64 * 81 + 4, device=DEV)
+    out = buf[1:1 + 16 * 64 * 64 * 81]
+    assert out.data_ptr() % 16 == 4
+    rc = _hip.lib().qpwc_cost_volume_fwd(p.data_ptr(), n.data_ptr(), out.data_ptr(), 16, 64, 64, 32, 4,
+                                         _hip.NHWC, _hip.F32, 0.1, torch.cuda.current_stream().cuda_stream)
+    _hip.check(rc)
+    np.testing.assert_allclose(out.view(16, 64, 64, 81).cpu().numpy(), c_ref.cost_volume(prv, nxt), atol=TOL)
