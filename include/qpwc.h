@@ -186,6 +186,19 @@ int qpwc_split_frames_pad_fwd(const void* in, void* out, int B, int H, int W, in
 int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, int dtype,
                              void* stream);
 
+/* inv_flow = -tf_warp(flow, flow) (occlusion.py:85; app/test/test_invert_flow.py:47): the flow
+ * field sampled at its own targets with the tf_warp rules (warp.py:63-153), negated.
+ * flow, out: (B,H,W,2) [NHWC] or (B,2,H,W) [NCHW], storage `dtype`, arithmetic fp32. */
+int qpwc_invert_flow_fwd(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
+                         void* stream);
+
+/* estimate_occlusion_map (occlusion.py:27-118): out (B,H,W) fp32, 1 where the pixel leaves the
+ * image under `flow` or is the target of no pixel under the inverse flow above
+ * (idx3 = clip(int32(p + inv_flow[p])), tensor_scatter_nd_min of zeros into ones), else 0.
+ * Two launches (fill, scatter); deterministic. */
+int qpwc_occlusion_fwd(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

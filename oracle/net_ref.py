@@ -116,6 +116,82 @@ class RefNet:
         return flos
 
 
+class RefInterpolator(RefNet):
+    """``build_interpolator`` (qpwcnet/core/pwcnet.py:247-281) + ``interpolator`` (:70-131) +
+    ``FrameInterpolate`` (non_layers.py:276-312), op for op on torch-CPU."""
+
+    def flower(self, enc_prv, enc_nxt, decs_prv, decs_nxt):      # non_layers.py:470-505
+        cost = torch_ref.cost_volume(enc_prv, enc_nxt)
+        flo = self.opt_flow("flow.flow.", torch.cat([cost, enc_prv, enc_nxt], dim=3))
+        flos = [flo]
+        for i in range(DEC):
+            flo_u = self.upsample(flo, 2.0)
+            prv, nxt = decs_prv[i], decs_nxt[i]
+            nxt_w = torch_ref.warp_v2(nxt, flo_u)
+            cost = torch_ref.cost_volume(prv, nxt_w)
+            flo = self.opt_flow("upflow.{}.flow.".format(i), torch.cat([cost, prv, flo_u], dim=3))
+            flos.append(flo)
+        flos.append(self.upsample(flo, 1.0))        # `Upsample(sacle=2.0)` keeps scale 1.0 (:468)
+        return flos
+
+    def frame_interpolate(self, k, prv, nxt, flo_01, flo_10, img_u=None):   # non_layers.py:294-312
+        nxt_w = torch_ref.warp_v2(nxt, 0.5 * flo_01)
+        prv_w = torch_ref.warp_v2(prv, 0.5 * flo_10)
+        feats = [prv_w, nxt_w, flo_01, flo_10] + ([] if img_u is None else [img_u])
+        x = _c(torch.cat(feats, dim=3))
+        p = "img.{}.".format(k)
+        dw = self.w[p + "conv1.depthwise.weight"]
+        x = F.conv2d(x, dw, None, padding=1, groups=dw.shape[0])
+        x = mish(F.conv2d(x, self.w[p + "conv1.pointwise.weight"], self.w[p + "conv1.bias"]))
+        return _l(F.conv2d(x, self.w[p + "conv2.weight"], self.w[p + "conv2.bias"]))
+
+    @staticmethod
+    def downsample(x):                              # AvgPool2D(2,2,'same'), non_layers.py:171-180
+        h, w = x.shape[1], x.shape[2]
+        y = _c(x)
+        ones = torch.ones((1, 1, h, w), dtype=x.dtype)
+        pad = (0, w % 2, 0, h % 2)                  # SAME: pad after; padding not counted
+        s = F.avg_pool2d(F.pad(y, pad), 2, divisor_override=1)
+        n = F.avg_pool2d(F.pad(ones, pad), 2, divisor_override=1)
+        return _l(s / n)
+
+    @torch.no_grad()
+    def __call__(self, inputs):
+        """inputs (B,H,W,6) -> list of the 6 multi-scale images (pwcnet.py:127-128)."""
+        x = torch.as_tensor(inputs).to(self.dtype)
+        img_prv, img_nxt = x[..., :3], x[..., 3:]
+        encs = []
+        for img in (img_prv, img_nxt):
+            f, feats = img, [img]
+            for i in range(ENC):
+                f = self.down_conv(i, f)
+                feats.append(f)
+            encs.append(feats)
+        decs = []
+        for feats in encs:
+            f, out, k = feats[-1], [], -2
+            for i in range(DEC):
+                f = torch.cat([self.up_conv(i, f), feats[k]], dim=3)
+                k -= 1
+                out.append(f)
+            decs.append(out)
+        flows_01 = self.flower(encs[1][-1], encs[0][-1], decs[1], decs[0])   # pwcnet.py:271
+        flows_10 = self.flower(encs[0][-1], encs[1][-1], decs[0], decs[1])   # pwcnet.py:277
+        imgs_prv, imgs_nxt = [img_prv], [img_nxt]
+        for _ in range(DEC + 1):                    # pwcnet.py:87-90
+            imgs_prv.append(self.downsample(imgs_prv[-1]))
+            imgs_nxt.append(self.downsample(imgs_nxt[-1]))
+        img = self.frame_interpolate(0, imgs_prv[-1], imgs_nxt[-1], flows_01[0], flows_10[0])
+        imgs = [img]
+        for i in range(DEC):                        # pwcnet.py:107-121
+            img_u = self.upsample(img, 1.0)
+            img = self.frame_interpolate(i + 1, decs[0][i], decs[1][i], flows_01[i + 1], flows_10[i + 1],
+                                         img_u)
+            imgs.append(img)
+        imgs.append(self.upsample(img, 1.0))        # pwcnet.py:124
+        return imgs
+
+
 def multiscale_gt(flow_gt, shapes):
     """Per-level ground truth of FlowMseLoss: bilinear resize to (h,w), times h/H
     (qpwcnet/train/loss.py:56-62)."""

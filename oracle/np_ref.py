@@ -211,3 +211,39 @@ def cost_volume_to_flow(cvol, data_format=CHANNELS_LAST):
     di = di - (q - 1) / 2
     dj = dj - (q - 1) / 2
     return np.stack([di, dj], axis=axis)
+
+
+def invert_flow(flow, data_format=CHANNELS_LAST):
+    """``inv_flow = -tf_warp(flow, flow, data_format)`` -- qpwcnet/core/occlusion.py:85,
+    qpwcnet/app/test/test_invert_flow.py:47."""
+    return -tf_warp(flow, flow, data_format)
+
+
+def estimate_occlusion_map(flow, data_format=CHANNELS_LAST):
+    """``estimate_occlusion_map`` -- qpwcnet/core/occlusion.py:27-118, op for op; (B,H,W) f32.
+
+    Unbatched input is an error in the reference (unbound ``is_batch``, occlusion.py:19-21)."""
+    flow = np.asarray(flow, dtype=np.float32)
+    if flow.ndim < 4:
+        raise ValueError("estimate_occlusion_map requires batched rank-4 input (occlusion.py:19-21)")
+    axis = -3 if data_format == CHANNELS_FIRST else -1          # occlusion.py:43-46
+    if data_format == CHANNELS_FIRST:
+        n, _, h, w = flow.shape
+    else:
+        n, h, w, _ = flow.shape
+    i, j = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")  # occlusion.py:50
+    i = i.astype(np.float32)
+    j = j.astype(np.float32)
+    dj, di = np.moveaxis(flow, axis, 0)                         # occlusion.py:59 (unstack)
+    i2, j2 = i + di, j + dj                                     # occlusion.py:60
+    oob = np.any([i2 < 0, i2 >= h, j2 < 0, j2 >= w], axis=0)    # occlusion.py:74
+    oob = oob.astype(np.float32)
+    inv_flow = invert_flow(flow, data_format)                   # occlusion.py:85
+    dj, di = np.moveaxis(inv_flow, axis, 0)
+    i2, j2 = i + di, j + dj
+    idx3 = np.stack([i2, j2], axis=-1).astype(np.int32)         # occlusion.py:88 (truncation)
+    idx3 = np.clip(idx3, [0, 0], [h - 1, w - 1])                # occlusion.py:89-92
+    b = np.broadcast_to(np.arange(n).reshape(n, 1, 1), (n, h, w))
+    map3 = np.ones_like(oob)                                    # occlusion.py:95 scatter_nd_min
+    np.minimum.at(map3, (b, idx3[..., 0], idx3[..., 1]), np.float32(0.0))
+    return np.maximum(oob, map3)                                # occlusion.py:98

@@ -53,6 +53,10 @@ int bias_mish_pad_launch(const void* src, const void* bias, void* dst, int B, in
                          int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, hipStream_t s);
 int split_frames_pad_launch(const void* in, void* out, int B, int H, int W, int pad_h, int pad_w, int dtype,
                             hipStream_t s);
+int invert_flow_launch(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
+                       hipStream_t s);
+int occlusion_launch(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
+                     hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
@@ -332,6 +336,36 @@ int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, con
     }
     return epe_multi_launch(y_true, y_pred, n_pixels, n_levels, (float*)out_means, (float*)workspace,
                             (hipStream_t)stream);
+}
+
+static int check_flow_args(const void* flow, const void* out, int B, int H, int W, int layout, int dtype,
+                           size_t out_bytes) {
+    if (!flow || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    const int rc = check_common(B, H, W, 2, layout, dtype);
+    if (rc) return rc;
+    const size_t es = esize(dtype);
+    if ((uintptr_t)flow % es || (uintptr_t)out % es)
+        return fail(QPWC_E_ALIGN, "pointer not element aligned");
+    if ((int64_t)B * H * W * 2 >= ((int64_t)1 << 40)) return fail(QPWC_E_SHAPE, "flow too large");
+    if (overlaps(out, out_bytes, flow, (size_t)B * H * W * 2 * es)) return fail(QPWC_E_ALIAS, "out overlaps flow");
+    return QPWC_OK;
+}
+
+int qpwc_invert_flow_fwd(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
+                         void* stream) {
+    const int rc = check_flow_args(flow, out, B, H, W, layout, dtype,
+                                   (size_t)(B > 0 ? B : 0) * (H > 0 ? H : 0) * (W > 0 ? W : 0) * 2 * esize(dtype));
+    if (rc) return rc;
+    return invert_flow_launch(flow, out, B, H, W, layout, dtype, (hipStream_t)stream);
+}
+
+int qpwc_occlusion_fwd(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
+                       void* stream) {
+    const int rc = check_flow_args(flow, out, B, H, W, layout, dtype,
+                                   (size_t)(B > 0 ? B : 0) * (H > 0 ? H : 0) * (W > 0 ? W : 0) * 4);
+    if (rc) return rc;
+    if ((uintptr_t)out % 4) return fail(QPWC_E_ALIGN, "out must be 4-byte aligned");
+    return occlusion_launch(flow, out, B, H, W, layout, dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -120,6 +120,16 @@ class Split(_Functor):
         return torch.chunk(x, self.num, dim=self.split_axis)
 
 
+class Downsample(_Functor):
+    """qpwcnet/core/non_layers.py:171-180: AvgPool2D(2x2, padding='same') -- TensorFlow's SAME
+    average pooling leaves the padding out of the divisor (== ceil_mode windows clipped at
+    the far edge)."""
+
+    def __call__(self, x):
+        y = F.avg_pool2d(self._nchw(x), 2, stride=2, ceil_mode=True, count_include_pad=False)
+        return self._fmt(y)
+
+
 class Upsample(_Functor):
     """qpwcnet/core/non_layers.py:183-193: scale * UpSampling2D(2, 'bilinear')
     (half-pixel centres == align_corners=False)."""
@@ -380,6 +390,101 @@ class UpFlow(_Weighted):
         feat[..., d2:d2 + C] = prv
         feat[..., d2 + C:] = flo
         return feat
+
+
+class FrameInterpolate(_Weighted):
+    """qpwcnet/core/non_layers.py:276-312 (Keras twin layers.py:356-402): both inputs warped half
+    way along their flows (WarpV2), concat [prv_w, nxt_w, flo_01, flo_10 (, img_u)] ->
+    SeparableConv2D(64, 3x3, 'same') + Mish -> Conv2D(3, 1x1).
+
+    On the HIP path (channels_last, CUDA tensors) the two big concat members are never copied:
+    the depthwise kernel reads [prv_w | nxt_w | small] as a virtual concat, the pointwise convs
+    are library GEMMs and bias+Mish is the HIP epilogue."""
+
+    FILTERS = 64
+
+    def __init__(self, params, prefix, up=False, *args, **kwargs):
+        kwargs.pop("name", None)  # the functor drops it too (non_layers.py:292)
+        super().__init__(params, prefix, *args, **kwargs)
+        self.up = bool(up)
+        self._config = {"up": self.up}
+        self.warp = WarpV2(data_format=self.data_format)
+
+    def get_config(self):
+        return dict(self._config)
+
+    def _hip_ok(self, tensors):
+        return (self.data_format == CHANNELS_LAST and
+                all(t.is_cuda and t.dtype in (torch.float32, torch.float16) for t in tensors))
+
+    def __call__(self, inputs):
+        if self.up:
+            prv, nxt, flo_01, flo_10, img_u = inputs
+        else:
+            prv, nxt, flo_01, flo_10 = inputs
+            img_u = None
+        nxt_w = self.warp((nxt, 0.5 * flo_01))   # "Applying half-scale flow is valid-ish"
+        prv_w = self.warp((prv, 0.5 * flo_10))
+        rest = [flo_01, flo_10] + ([img_u] if self.up else [])
+        return self.head(prv_w, nxt_w, rest)
+
+    def head(self, prv_w, nxt_w, rest):
+        """conv2(conv1(concat[prv_w, nxt_w, *rest]))."""
+        dw = self.p("conv1.depthwise.weight")
+        pw = self.p("conv1.pointwise.weight")
+        w2 = self.p("conv2.weight")
+        if self._hip_ok([prv_w, nxt_w] + list(rest)):
+            B, H, W = prv_w.shape[:3]
+            small = torch.cat(list(rest), dim=3)
+            if prv_w.shape[3] % 4:   # tiny image-level block: one dense source
+                src = [torch.cat([prv_w, nxt_w, small], dim=3)]
+            else:
+                src = [prv_w, nxt_w, small]
+            y = ops.dwconv3x3(src, self.p32("conv1.depthwise.weight").reshape(-1, 9))
+            key = self.prefix + "#gemm"
+            mats = self.params.get(key)
+            if mats is None:
+                mats = self.params[key] = (pw.reshape(pw.shape[0], -1).t().contiguous(),
+                                           w2.reshape(w2.shape[0], -1).t().contiguous())
+            z = torch.mm(y.view(B * H * W, -1), mats[0]).view(B, H, W, -1)
+            ops.bias_mish_(z, self.p32("conv1.bias"))
+            return torch.addmm(self.p("conv2.bias"), z.view(B * H * W, -1), mats[1]).view(B, H, W, -1)
+        x = self._nchw(torch.cat([prv_w, nxt_w] + list(rest), dim=self.axis))
+        x = F.conv2d(x, dw, None, stride=1, padding=1, groups=dw.shape[0])
+        x = F.mish(F.conv2d(x, pw, self.p("conv1.bias")))
+        return self._fmt(F.conv2d(x, w2, self.p("conv2.bias")))
+
+
+class Flower(_Weighted):
+    """qpwcnet/core/non_layers.py:452-505: the flow stack as one callable, so that
+    ``build_interpolator`` can run it twice with shared weights (pwcnet.py:268-278).
+    The last upsampler is built with the misspelt keyword ``sacle=2.0`` (:468) and therefore
+    keeps scale 1.0 -- reproduced: only the final, upsample-only flow is affected."""
+
+    def __init__(self, params, num_layers, output_multiscale=True, use_tfa=True, hip_optflow=True,
+                 *args, **kwargs):
+        super().__init__(params, "", *args, **kwargs)
+        df = self.data_format
+        self.num_layers = num_layers
+        self.output_multiscale = output_multiscale
+        self.use_tfa = use_tfa
+        self.flow = Flow(params, "flow.", use_tfa=use_tfa, hip_optflow=hip_optflow, data_format=df)
+        self.upsamples = [Upsample(scale=2.0, data_format=df) for _ in range(num_layers)]
+        self.upflows = [UpFlow(params, "upflow.{}.".format(i), use_tfa=use_tfa, hip_optflow=hip_optflow,
+                               data_format=df) for i in range(num_layers)]
+        self.upsamples.append(Upsample(sacle=2.0, data_format=df))
+
+    def __call__(self, inputs):
+        enc_prv, enc_nxt, decs_prv, decs_nxt = inputs
+        flo_01 = self.flow((enc_prv, enc_nxt))
+        flos = [flo_01]
+        for i in range(self.num_layers):
+            flo_01_u = self.upsamples[i](flo_01)
+            flo_01 = self.upflows[i]((decs_prv[i], decs_nxt[i], flo_01_u))
+            flos.append(flo_01)
+        flo_01 = self.upsamples[-1](flo_01)
+        flos.append(flo_01)
+        return flos if self.output_multiscale else [flo_01]
 
 
 def scale_of(h, w):

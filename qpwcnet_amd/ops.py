@@ -334,6 +334,47 @@ def upsample2x_flow(flo, scale=1.0):
     return out
 
 
+def _flow_dims(flow, data_format):
+    get_axis(data_format)
+    if flow.dim() != 4:
+        raise ValueError("flow must be a batched rank-4 tensor, got rank {}".format(flow.dim()))
+    if data_format == CHANNELS_LAST:
+        B, H, W, C = flow.shape
+        layout = _hip.NHWC
+    else:
+        B, C, H, W = flow.shape
+        layout = _hip.NCHW
+    if C != 2:
+        raise ValueError("flow must have 2 channels, got {}".format(C))
+    return B, H, W, layout
+
+
+def invert_flow(flow, data_format=CHANNELS_LAST):
+    """-tf_warp(flow, flow) (qpwcnet/core/occlusion.py:85; app/test/test_invert_flow.py:47)."""
+    _check_tensor("flow", flow)
+    B, H, W, layout = _flow_dims(flow, data_format)
+    f = flow.contiguous()
+    out = torch.empty_like(f)
+    with torch.cuda.device(f.device), _timed("invert_flow", (B, H, W, 2)):
+        rc = _hip.lib().qpwc_invert_flow_fwd(f.data_ptr(), out.data_ptr(), B, H, W, layout,
+                                             _DTYPES[f.dtype], _stream(f))
+    _hip.check(rc)
+    return out
+
+
+def occlusion_map(flow, data_format=CHANNELS_LAST):
+    """estimate_occlusion_map (qpwcnet/core/occlusion.py:27-118) -> (B,H,W) float32."""
+    _check_tensor("flow", flow)
+    B, H, W, layout = _flow_dims(flow, data_format)
+    f = flow.contiguous()
+    out = torch.empty((B, H, W), dtype=torch.float32, device=f.device)
+    with torch.cuda.device(f.device), _timed("occlusion", (B, H, W, 2)):
+        rc = _hip.lib().qpwc_occlusion_fwd(f.data_ptr(), out.data_ptr(), B, H, W, layout,
+                                           _DTYPES[f.dtype], _stream(f))
+    _hip.check(rc)
+    return out
+
+
 def epe_multi(flows_true, flows_pred):
     """Per-level EPE of up to 8 channels-last fp32 flow pairs in two launches
     (FlowMseLoss, qpwcnet/train/loss.py:56-67) -> float32 tensor [n_levels]."""

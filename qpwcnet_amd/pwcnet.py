@@ -9,8 +9,9 @@ import torch
 
 from . import ops
 from .backend import CHANNELS_FIRST, CHANNELS_LAST, get_axis, image_data_format
-from .non_layers import DownConv, Flow, Split, UpConv, UpFlow, Upsample
-from .synth import DEC_FILTERS, ENC_FILTERS, make_weights
+from .non_layers import (DownConv, Downsample, Flow, Flower, FrameInterpolate, Split, UpConv, UpFlow,
+                         Upsample)
+from .synth import DEC_FILTERS, ENC_FILTERS, make_interpolator_weights, make_weights
 
 
 def encoder(layers, img_prv, img_nxt, output_features=False):
@@ -60,6 +61,29 @@ def flower(flow, upflows, enc_prv, enc_nxt, decs_prv, decs_nxt, data_format,
     flo_01 = Upsample(scale=2.0, data_format=data_format)(flo_01)
     flos.append(flo_01)
     return flos if output_multiscale else [flo_01]
+
+
+def interpolator(blocks, img_prv, img_nxt, decs_prv, decs_nxt, flos_01, flos_10, data_format,
+                 output_multiscale=True):
+    """pwcnet.py:70-131: frame-interpolation stack.  `blocks`: the n+1 FrameInterpolate functors
+    (img_0 ... img_n).  The coarsest image comes from the twice-per-level average-pooled input
+    frames, every finer one from the decoder features of that level plus the upsampled previous
+    image; the full-resolution output is upsample-only (:123-124)."""
+    n = len(decs_prv)
+    pool = Downsample(data_format=data_format)
+    up = Upsample(scale=1.0, data_format=data_format)
+    imgs_prv, imgs_nxt = [img_prv], [img_nxt]
+    for _ in range(n + 1):                                   # :87-90
+        imgs_prv.append(pool(imgs_prv[-1]))
+        imgs_nxt.append(pool(imgs_nxt[-1]))
+    img = blocks[0]((imgs_prv[-1], imgs_nxt[-1], flos_01[0], flos_10[0]))   # :101-102
+    imgs = [img]
+    for i in range(n):                                       # :107-121
+        img_u = up(img)
+        img = blocks[i + 1]((decs_prv[i], decs_nxt[i], flos_01[i + 1], flos_10[i + 1], img_u))
+        imgs.append(img)
+    imgs.append(up(img))                                     # :124
+    return imgs if output_multiscale else imgs[-1]
 
 
 class QpwcNet:
@@ -205,6 +229,61 @@ class GraphedForward:
             self.static_in.copy_(inputs)
         self.graph.replay()
         return self.outputs, self.extra
+
+
+class QpwcInterpolator(QpwcNet):
+    """What ``build_interpolator`` returns (pwcnet.py:247-281): encoder/decoder as in
+    ``build_flower``, the Flower block run in both directions with shared weights --
+    ``flows_01 = flower(enc_nxt, enc_prv, decs_nxt, decs_prv)``, ``flows_10`` with the roles
+    swapped (:271-278, argument order as written there) -- then the interpolation stack.
+    Returns the list of n+2 images (coarse to fine, last = full resolution) or only the last."""
+
+    def __init__(self, weights, input_shape=(256, 512), data_format=None, use_tfa=True,
+                 output_multiscale=True, device="cuda", dtype=torch.float32, hip_optflow=True):
+        super().__init__(weights, train=True, input_shape=input_shape, data_format=data_format,
+                         use_tfa=use_tfa, device=device, dtype=dtype, hip_optflow=hip_optflow,
+                         batch_frames=True, overlap_streams=False)
+        df = self.data_format
+        self.output_multiscale = bool(output_multiscale)
+        self.flower_block = Flower(self.params, len(DEC_FILTERS), output_multiscale=True, use_tfa=use_tfa,
+                                   hip_optflow=hip_optflow, data_format=df)
+        self.img_blocks = [FrameInterpolate(self.params, "img.{}.".format(k), up=k > 0, data_format=df)
+                           for k in range(len(DEC_FILTERS) + 1)]
+
+    def __call__(self, inputs):
+        exp = (self.input_shape + (6,)) if self.data_format == CHANNELS_LAST \
+            else ((6,) + self.input_shape)
+        if tuple(inputs.shape[1:]) != exp:
+            raise ValueError("expected input shape (B,)+{}, got {}".format(exp, tuple(inputs.shape)))
+        img_prv, img_nxt = self.split(inputs)
+        nb = inputs.shape[0]
+        # shared encoder/decoder weights: both frames as one batch of 2B (as in QpwcNet)
+        f = torch.cat([img_prv, img_nxt], dim=0)
+        encs = [f]
+        for l in self.enc:
+            f = l(f)
+            encs.append(f)
+        decs, i = [], -2
+        for l in self.dec:
+            f = l.cat_skip(f, encs[i])
+            i -= 1
+            decs.append(f)
+        enc_prv, enc_nxt = encs[-1][:nb], encs[-1][nb:]
+        decs_prv, decs_nxt = [d[:nb] for d in decs], [d[nb:] for d in decs]
+        flows_01 = self.flower_block((enc_nxt, enc_prv, decs_nxt, decs_prv))
+        flows_10 = self.flower_block((enc_prv, enc_nxt, decs_prv, decs_nxt))
+        return interpolator(self.img_blocks, img_prv, img_nxt, decs_prv, decs_nxt, flows_01, flows_10,
+                            self.data_format, self.output_multiscale)
+
+
+def build_interpolator(input_shape=(256, 512), data_format=None, use_tfa=True, weights=None,
+                       output_multiscale=True, device="cuda", dtype=torch.float32, hip_optflow=True):
+    """pwcnet.py:247-281.  ``weights``: flat dict from ``synth.make_interpolator_weights``."""
+    if weights is None:
+        weights = make_interpolator_weights(42, input_shape)
+    return QpwcInterpolator(weights, input_shape=input_shape, data_format=data_format, use_tfa=use_tfa,
+                            output_multiscale=output_multiscale, device=device, dtype=dtype,
+                            hip_optflow=hip_optflow)
 
 
 def build_flower(train=True, input_shape=(256, 512), data_format=None, use_tfa=True,

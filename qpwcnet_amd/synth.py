@@ -93,6 +93,27 @@ def make_weights(seed=42, input_shape=(256, 512), flow_gain=30.0):
     return w
 
 
+INTERP_FILTERS = 64   # FrameInterpolate.conv1, non_layers.py:283-285
+
+
+def make_interpolator_weights(seed=42, input_shape=(256, 512), flow_gain=30.0):
+    """``build_interpolator`` (pwcnet.py:247-281): the ``build_flower`` parameters plus the five
+    FrameInterpolate blocks img_0..img_4 (SeparableConv2D 64 + Conv2D 3, non_layers.py:283-293).
+    Input channels: img_0 = 3+3+2+2; img_k = 2*C_dec + 2 + 2 + 3 (pwcnet.py:101-121)."""
+    w = make_weights(seed, input_shape, flow_gain)
+    rng = np.random.default_rng(seed + 1000)
+    chans = level_channels()
+    cins = [3 + 3 + 2 + 2] + [2 * chans[k] + 2 + 2 + 3 for k in range(1, 5)]
+    for k, c in enumerate(cins):
+        p = "img.{}.".format(k)
+        w[p + "conv1.depthwise.weight"] = _glorot(rng, (c, 1, 3, 3), c * 9, 9)
+        w[p + "conv1.pointwise.weight"] = _glorot(rng, (INTERP_FILTERS, c, 1, 1), c, INTERP_FILTERS)
+        w[p + "conv1.bias"] = _bias(rng, INTERP_FILTERS)
+        w[p + "conv2.weight"] = _glorot(rng, (3, INTERP_FILTERS, 1, 1), INTERP_FILTERS, 3, gain=1.0)
+        w[p + "conv2.bias"] = _bias(rng, 3)
+    return w
+
+
 def _bilinear_sample(img, yq, xq):
     """Clamp-to-border bilinear sampling in numpy (data generation only)."""
     H, W = img.shape[:2]

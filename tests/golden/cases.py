@@ -72,3 +72,34 @@ def sample_indices(name, out_size):
     rng = np.random.default_rng(1000 + seed)
     n = min(N_SAMPLES, out_size)
     return np.sort(rng.choice(out_size, size=n, replace=False))
+
+
+# ---- inverse flow / occlusion map (qpwcnet/core/occlusion.py) -------------
+# name -> (data_format, flow shape, seed, noise sigma, smooth amplitude)
+OCC_CASES = {
+    "occ_nhwc": ("channels_last", (2, 32, 64, 2), 40, 1.0, 6.0),
+    "occ_nchw": ("channels_first", (2, 2, 32, 64), 41, 1.0, 6.0),
+    "occ_ragged": ("channels_last", (3, 19, 37, 2), 42, 0.5, 10.0),
+    "occ_smooth_L4": ("channels_last", (1, 128, 256, 2), 43, 0.0, 8.0),
+    "occ_noise": ("channels_last", (1, 24, 40, 2), 44, 4.0, 0.0),
+}
+
+
+def make_flow(name):
+    """fp32 flow: smooth low-frequency field (amplitude `amp` px) + N(0, sigma) noise; leaves the
+    image near the borders, folds over itself where the noise is large."""
+    fmt, shape, seed, sigma, amp = OCC_CASES[name]
+    rng = np.random.default_rng(seed)
+    if fmt == "channels_last":
+        n, h, w, _ = shape
+    else:
+        n, _, h, w = shape
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    f = np.empty((n, h, w, 2), np.float64)
+    for b in range(n):
+        ph = rng.uniform(0, 2 * np.pi, size=4)
+        f[b, ..., 0] = amp * np.sin(2 * np.pi * yy / h + ph[0]) * np.cos(2 * np.pi * xx / w + ph[1])
+        f[b, ..., 1] = amp * np.cos(2 * np.pi * yy / h + ph[2]) * np.sin(2 * np.pi * xx / w + ph[3])
+    f += rng.standard_normal(f.shape) * sigma
+    f = f.astype(np.float32)
+    return f if fmt == "channels_last" else np.ascontiguousarray(np.moveaxis(f, 3, 1))

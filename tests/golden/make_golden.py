@@ -47,6 +47,18 @@ def main():
     np.savez_compressed(os.path.join(HERE, "known_3x3.npz"), nxt=nxt, flo=flo,
                         warp_v2=np_ref.warp_v2(nxt, flo), tf_warp=np_ref.tf_warp(nxt, flo))
 
+    # inverse flow / occlusion maps (fp32 by definition: occlusion.py:56-57 casts to float32):
+    # full uint8 map + the inverse flow
+    for name in cases.OCC_CASES:
+        fmt = cases.OCC_CASES[name][0]
+        flow = cases.make_flow(name)
+        occ = np_ref.estimate_occlusion_map(flow, fmt)
+        inv = np_ref.invert_flow(flow, fmt)
+        assert set(np.unique(occ)) <= {0.0, 1.0}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), occ=occ.astype(np.uint8),
+                            inv=inv.astype(np.float32))
+        print(name, occ.shape, float(occ.mean()))
+
 
 if __name__ == "__main__":
     main()

@@ -129,3 +129,52 @@ def test_keras_layout_round_trip(tmp_path):
     W.save_npz(str(p), w)
     again = W.load_npz(str(p))
     assert all(np.array_equal(again[n], w[n]) for n in w)
+
+
+# ---- occlusion / frame interpolation host logic --------------------------
+def test_downsample_is_tf_same_average_pooling():
+    from oracle.net_ref import RefInterpolator
+    from qpwcnet_amd.non_layers import Downsample
+    x = torch.arange(2 * 5 * 7 * 3, dtype=torch.float32).reshape(2, 5, 7, 3)
+    y = Downsample(data_format="channels_last")(x)
+    assert tuple(y.shape) == (2, 3, 4, 3)
+    assert torch.allclose(y, RefInterpolator.downsample(x))
+    # last window of an odd extent averages only the cells inside the image
+    assert torch.allclose(y[:, 2, 3], x[:, 4, 6])
+    yc = Downsample(data_format="channels_first")(x.permute(0, 3, 1, 2))
+    assert torch.equal(yc.permute(0, 2, 3, 1), y)
+
+
+def test_flower_keeps_the_reference_typo():
+    from qpwcnet_amd.non_layers import Flower
+    fl = Flower({}, 4, data_format="channels_last")
+    assert [u.scale for u in fl.upsamples] == [2.0, 2.0, 2.0, 2.0, 1.0]   # non_layers.py:464-468
+    assert len(fl.upflows) == 4
+
+
+def test_interpolator_weights_and_no_cpu_fallback():
+    from qpwcnet_amd.non_layers import FrameInterpolate
+    from qpwcnet_amd.synth import make_interpolator_weights, make_weights
+    w = make_interpolator_weights(42, (64, 128))
+    base = make_weights(42, (64, 128))
+    assert all(np.array_equal(w[k], base[k]) for k in base)       # build_flower part unchanged
+    cins = [w["img.{}.conv1.depthwise.weight".format(k)].shape[0] for k in range(5)]
+    assert cins == [10, 519, 263, 135, 71]                        # pwcnet.py:101-121
+    assert w["img.0.conv2.weight"].shape == (3, 64, 1, 1)
+    params = {k: torch.from_numpy(v) for k, v in w.items()}
+    blk = FrameInterpolate(params, "img.0.", up=False, name="img_0", data_format="channels_last")
+    assert blk.get_config() == {"up": False}
+    z = torch.zeros((1, 4, 6, 3))
+    f = torch.zeros((1, 4, 6, 2))
+    with pytest.raises(RuntimeError):                             # WarpV2 is HIP-only
+        blk((z, z, f, f))
+
+
+def test_occlusion_host_errors():
+    from qpwcnet_amd import occlusion
+    assert occlusion.get_spatial_shape(torch.zeros((2, 5, 7, 2)), "channels_last") == {"n": 2, "h": 5, "w": 7}
+    assert occlusion.get_spatial_shape(torch.zeros((2, 2, 5, 7)), "channels_first") == {"n": 2, "h": 5, "w": 7}
+    with pytest.raises(ValueError):
+        occlusion.get_spatial_shape(torch.zeros((5, 7, 2)), "channels_last")
+    with pytest.raises(RuntimeError):
+        occlusion.estimate_occlusion_map(torch.zeros((1, 5, 7, 2)), "channels_last")

@@ -182,3 +182,59 @@ def test_torch_restatement_matches_numpy():
     np.testing.assert_array_equal(torch_ref.tf_warp(ta, tf_).numpy(), np_ref.tf_warp(a, f))
     assert abs(float(torch_ref.epe_error(ta[..., :2], tb[..., :2])) -
                np_ref.epe_error(a[..., :2], b[..., :2])) < 1e-6
+
+
+# ---- inverse flow / occlusion map ------------------------------------------
+@pytest.mark.parametrize("name", sorted(cases.OCC_CASES))
+def test_occlusion_oracle_matches_golden(name):
+    fmt = cases.OCC_CASES[name][0]
+    flow = cases.make_flow(name)
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert np.array_equal(np_ref.estimate_occlusion_map(flow, fmt), gold["occ"].astype(np.float32))
+    assert np.array_equal(np_ref.invert_flow(flow, fmt), gold["inv"])
+
+
+def _occlusion_loops(flow):
+    """Scalar restatement of occlusion.py:50-98 (channels_last), pixel by pixel."""
+    n, h, w, _ = flow.shape
+    f32 = np.float32
+    inv = np_ref.invert_flow(flow)
+    out = np.ones((n, h, w), np.float32)
+    for b in range(n):
+        for i in range(h):
+            for j in range(w):
+                ti = min(max(int(f32(i) + inv[b, i, j, 1]), 0), h - 1)   # int(): truncation
+                tj = min(max(int(f32(j) + inv[b, i, j, 0]), 0), w - 1)
+                out[b, ti, tj] = 0.0
+    for b in range(n):
+        for i in range(h):
+            for j in range(w):
+                i2, j2 = f32(i) + flow[b, i, j, 1], f32(j) + flow[b, i, j, 0]
+                if i2 < 0 or i2 >= h or j2 < 0 or j2 >= w:
+                    out[b, i, j] = 1.0
+    return out
+
+
+def test_occlusion_oracle_against_scalar_loops():
+    flow = cases.make_flow("occ_noise")
+    assert np.array_equal(np_ref.estimate_occlusion_map(flow), _occlusion_loops(flow))
+
+
+def test_occlusion_known_answers_and_layouts():
+    z = np.zeros((2, 5, 7, 2), np.float32)
+    assert not np_ref.estimate_occlusion_map(z).any()          # zero flow: nothing occluded
+    f = np.zeros((1, 6, 12, 2), np.float32)
+    f[..., 0] = 2.0                                            # everything moves 2 px right
+    occ = np_ref.estimate_occlusion_map(f)
+    assert (occ[0, :, -2:] == 1).all()                         # the last two columns leave the image
+    # inverse of a uniform shift is the opposite shift, except where tf_warp's far-border
+    # rule (weights vanish at x >= W-1 and on the last row, SURVEY 8(a) A4) zeroes the sample
+    inv = np_ref.invert_flow(f)
+    assert (inv[0, :-1, :9, 0] == -2).all() and (inv[0, :, 9:, 0] == 0).all() and (inv[0, -1] == 0).all()
+    assert (inv[..., 1] == 0).all()
+    flow = cases.make_flow("occ_nhwc")
+    nchw = np.ascontiguousarray(np.moveaxis(flow, 3, 1))
+    assert np.array_equal(np_ref.estimate_occlusion_map(flow),
+                          np_ref.estimate_occlusion_map(nchw, "channels_first"))
+    with pytest.raises(ValueError):
+        np_ref.estimate_occlusion_map(flow[0])
