@@ -52,6 +52,11 @@ def main():
         if "fused" in a.ops and l > 0:
             cases.append(("fused L%d" % l, lambda p=prv, q=nxt, f=flo: ops.warp_cost_volume(p, q, f),
                           n * ((2 * C + 81) * es + 8)))
+    if "occ" in a.ops:   # full-resolution flow, 12 B per pixel
+        flo = torch.randn(a.batch, H0, W0, 2, device=dev, generator=g) * 3
+        n = a.batch * H0 * W0
+        cases.append(("occlusion %dx%d" % (H0, W0), lambda f=flo: ops.occlusion_map(f), n * 12))
+        cases.append(("invert_flow %dx%d" % (H0, W0), lambda f=flo: ops.invert_flow(f), n * 16))
     times = {c[0]: [] for c in cases}
     for name, fn, _ in cases:  # warm-up
         for _ in range(3):
