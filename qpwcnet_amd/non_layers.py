@@ -428,6 +428,13 @@ class FrameInterpolate(_Weighted):
         rest = [flo_01, flo_10] + ([img_u] if self.up else [])
         return self.head(prv_w, nxt_w, rest)
 
+    def call_stacked(self, swapped, flows, nb, img_u=None):
+        """Same block with both warps in one launch: `swapped` = [nxt; prv] and `flows` =
+        [flo_01; flo_10] stacked on the batch axis (2*nb)."""
+        w = self.warp((swapped, 0.5 * flows))            # [nxt_w; prv_w]
+        rest = [flows[:nb], flows[nb:]] + ([img_u] if self.up else [])
+        return self.head(w[nb:], w[:nb], rest)
+
     def head(self, prv_w, nxt_w, rest):
         """conv2(conv1(concat[prv_w, nxt_w, *rest]))."""
         dw = self.p("conv1.depthwise.weight")

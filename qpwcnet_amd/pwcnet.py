@@ -127,22 +127,9 @@ class QpwcNet:
             raise ValueError("expected input shape (B,)+{}, got {}".format(exp, tuple(inputs.shape)))
         img_prv, img_nxt = self.split(inputs)
         if self.batch_frames:
-            # The encoder/decoder weights are shared by both frames (pwcnet.py:145-162,
-            # 179-206): run them once on the 2B stacked frames, then split by views.
             nb = inputs.shape[0]
-            h, w = self.input_shape
-            if (self.data_format == CHANNELS_LAST and inputs.is_cuda and h % 2 == 0 and w % 2 == 0 and
-                    inputs.dtype in (torch.float32, torch.float16)):
-                # split + stack + 'SAME' padding of the first stride-2 conv in one pass
-                padded = ops.split_frames_pad(inputs, 1, 1)
-                f = padded[:, :h, :w, :]
-            else:
-                f, padded = torch.cat([img_prv, img_nxt], dim=0), None
-            encs = [f]
-            for li, l in enumerate(self.enc):
-                # the activation epilogue of level li lays down the 'SAME' padding level li+1 needs
-                f, padded = l.forward_padded(f, padded, want_padded=li + 1 < len(self.enc))
-                encs.append(f)
+            encs = self._encode_stacked(inputs, img_prv, img_nxt)
+            f = encs[-1]
             if self.overlap_streams and inputs.is_cuda:
                 return self._forward_two_streams(encs, nb)
             decs, i = [], -2
@@ -158,6 +145,24 @@ class QpwcNet:
         outs = flower(self.flow, self.upflows, encs_prv[-1], encs_nxt[-1], decs_prv, decs_nxt,
                       self.data_format, output_multiscale=self.train)
         return outs if self.train else outs[0]
+
+    def _encode_stacked(self, inputs, img_prv, img_nxt):
+        """The encoder/decoder weights are shared by both frames (pwcnet.py:145-162, 179-206): run
+        the encoder once on the 2B stacked frames [prv; nxt] -> [frames, enc_0 .. enc_4]."""
+        h, w = self.input_shape
+        if (self.data_format == CHANNELS_LAST and inputs.is_cuda and h % 2 == 0 and w % 2 == 0 and
+                inputs.dtype in (torch.float32, torch.float16)):
+            # split + stack + 'SAME' padding of the first stride-2 conv in one pass
+            padded = ops.split_frames_pad(inputs, 1, 1)
+            f = padded[:, :h, :w, :]
+        else:
+            f, padded = torch.cat([img_prv, img_nxt], dim=0), None
+        encs = [f]
+        for li, l in enumerate(self.enc):
+            # the activation epilogue of level li lays down the 'SAME' padding level li+1 needs
+            f, padded = l.forward_padded(f, padded, want_padded=li + 1 < len(self.enc))
+            encs.append(f)
+        return encs
 
     def _forward_two_streams(self, encs, nb):
         """Decoder chain on a side stream, flow chain on the caller's stream: the coarse
@@ -239,12 +244,14 @@ class QpwcInterpolator(QpwcNet):
     Returns the list of n+2 images (coarse to fine, last = full resolution) or only the last."""
 
     def __init__(self, weights, input_shape=(256, 512), data_format=None, use_tfa=True,
-                 output_multiscale=True, device="cuda", dtype=torch.float32, hip_optflow=True):
+                 output_multiscale=True, device="cuda", dtype=torch.float32, hip_optflow=True,
+                 batch_directions=True):
         super().__init__(weights, train=True, input_shape=input_shape, data_format=data_format,
                          use_tfa=use_tfa, device=device, dtype=dtype, hip_optflow=hip_optflow,
                          batch_frames=True, overlap_streams=False)
         df = self.data_format
         self.output_multiscale = bool(output_multiscale)
+        self.batch_directions = bool(batch_directions)
         self.flower_block = Flower(self.params, len(DEC_FILTERS), output_multiscale=True, use_tfa=use_tfa,
                                    hip_optflow=hip_optflow, data_format=df)
         self.img_blocks = [FrameInterpolate(self.params, "img.{}.".format(k), up=k > 0, data_format=df)
@@ -258,16 +265,15 @@ class QpwcInterpolator(QpwcNet):
         img_prv, img_nxt = self.split(inputs)
         nb = inputs.shape[0]
         # shared encoder/decoder weights: both frames as one batch of 2B (as in QpwcNet)
-        f = torch.cat([img_prv, img_nxt], dim=0)
-        encs = [f]
-        for l in self.enc:
-            f = l(f)
-            encs.append(f)
+        encs = self._encode_stacked(inputs, img_prv, img_nxt)
+        f = encs[-1]
         decs, i = [], -2
         for l in self.dec:
             f = l.cat_skip(f, encs[i])
             i -= 1
             decs.append(f)
+        if self.batch_directions and self.data_format == CHANNELS_LAST:
+            return self._both_directions_batched(img_prv, img_nxt, encs[-1], decs, nb)
         enc_prv, enc_nxt = encs[-1][:nb], encs[-1][nb:]
         decs_prv, decs_nxt = [d[:nb] for d in decs], [d[nb:] for d in decs]
         flows_01 = self.flower_block((enc_nxt, enc_prv, decs_nxt, decs_prv))
@@ -276,14 +282,39 @@ class QpwcInterpolator(QpwcNet):
                             self.data_format, self.output_multiscale)
 
 
+    def _both_directions_batched(self, img_prv, img_nxt, enc, decs, nb):
+        """The two Flower passes (shared weights, roles swapped: pwcnet.py:271-278) as ONE pass over
+        2*nb pairs -- pair b is (prv-role = nxt_b, nxt-role = prv_b), pair nb+b the opposite -- and
+        the two half-flow warps of every FrameInterpolate block as one launch.  Same arithmetic per
+        pair; half the launches on the launch-bound coarse levels."""
+        def swap(x):
+            return torch.cat([x[nb:], x[:nb]], dim=0)
+        enc_s, decs_s = swap(enc), [swap(d) for d in decs]
+        flows = self.flower_block((enc_s, enc, decs_s, decs))     # [flows_01; flows_10] per level
+        n = len(decs)
+        pool = Downsample(data_format=self.data_format)
+        up = Upsample(scale=1.0, data_format=self.data_format)
+        small = torch.cat([img_nxt, img_prv], dim=0)              # [nxt; prv], pwcnet.py:87-90
+        for _ in range(n + 1):
+            small = pool(small)
+        img = self.img_blocks[0].call_stacked(small, flows[0], nb)
+        imgs = [img]
+        for i in range(n):
+            img = self.img_blocks[i + 1].call_stacked(decs_s[i], flows[i + 1], nb, up(img))
+            imgs.append(img)
+        imgs.append(up(img))
+        return imgs if self.output_multiscale else imgs[-1]
+
+
 def build_interpolator(input_shape=(256, 512), data_format=None, use_tfa=True, weights=None,
-                       output_multiscale=True, device="cuda", dtype=torch.float32, hip_optflow=True):
+                       output_multiscale=True, device="cuda", dtype=torch.float32, hip_optflow=True,
+                       batch_directions=True):
     """pwcnet.py:247-281.  ``weights``: flat dict from ``synth.make_interpolator_weights``."""
     if weights is None:
         weights = make_interpolator_weights(42, input_shape)
     return QpwcInterpolator(weights, input_shape=input_shape, data_format=data_format, use_tfa=use_tfa,
                             output_multiscale=output_multiscale, device=device, dtype=dtype,
-                            hip_optflow=hip_optflow)
+                            hip_optflow=hip_optflow, batch_directions=batch_directions)
 
 
 def build_flower(train=True, input_shape=(256, 512), data_format=None, use_tfa=True,

@@ -32,6 +32,11 @@ def test_interpolator_images_match_oracle(hw, batch):
     last = build_interpolator(hw, "channels_last", weights=weights, device=DEV,
                               output_multiscale=False).predict(pairs)
     assert torch.allclose(last, imgs[-1], rtol=0, atol=1e-5)
+    # the reference's two separate Flower passes (pwcnet.py:271-278) instead of one batched pass
+    two = build_interpolator(hw, "channels_last", weights=weights, device=DEV,
+                             batch_directions=False).predict(pairs)
+    for a, b in zip(two, ref):
+        assert float((a.cpu() - b).abs().max()) < TOL
 
 
 def test_interpolator_channels_first():
