@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqpwc_hip.so")
+# QPWC_HIP_LIB: another build of the same library (kernel A/B experiments); default = in-tree build
+LIB_PATH = os.environ.get("QPWC_HIP_LIB") or os.path.join(_HERE, "csrc", "libqpwc_hip.so")
 
 NHWC, NCHW = 0, 1
 F32, F16 = 0, 1

@@ -26,6 +26,7 @@
 // Coarse levels have few pixels and many channels (8x16x256): KS waves of a
 // workgroup split the channel range of one tile (split-K) and their partial
 // frames are summed during the read-back, so every level fills the chip.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -46,50 +47,90 @@ constexpr int kRowStep = 4 * kFramePS + 12;   // frame offset of the next tile r
 // the dense case stores 4 consecutive output floats per lane: a tile row of 324 floats
 // is 81 x 16 B, rows are 16-byte aligned when W % 4 == 0, and a wave needs 8 store
 // instructions instead of 24.  All LDS reads are issued before the first use.
-template <typename T>
-__device__ __forceinline__ void store_tile(const float* fr, T* ob, int lane, int x0, int y0, int H,
-                                           int W, int out_pix_stride, float slope, float inv_c,
-                                           float cf) {
-    const int row_stride = W * out_pix_stride;
-    if (out_pix_stride == 81 && (W & 3) == 0 && x0 + 4 <= W && y0 + 4 <= H &&
-        (reinterpret_cast<uintptr_t>(ob) & (4 * sizeof(T) - 1)) == 0) {  // wave-uniform
-        // lane owns elements 4*q .. 4*q+3 of the 324-float row, q = lane (+64 for lanes 0..16)
-        int foff[2][4];
-#pragma unroll
+// Frame byte offsets of the four consecutive output floats 4q..4q+3 of a tile row (q = lane and
+// lane + 64): element e = 81*px + 9*ky + kx of the 4 px x 81 row sits at frame float
+// px*(kFramePS+1) + 12*ky + kx.  A per-lane table (one 16-byte load) replaces ~100 vector-ALU
+// instructions of constant divisions per wave -- the SIMD's issue slots are the contended resource
+// here (matrix cores 53 % + vector ALU ~35 % busy on the same SIMD).
+struct FoffTable {
+    unsigned short v[64][8];
+};
+constexpr FoffTable make_foff_table() {
+    FoffTable t{};
+    for (int lane = 0; lane < 64; ++lane)
         for (int it = 0; it < 2; ++it) {
             const int q = lane + 64 * it;
             const int qq = q < 81 ? q : 0;
-#pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int e = 4 * qq + c;
                 const int epx = e / 81, k = e - 81 * epx;
                 const int ky = k / 9, kx = k - 9 * ky;
-                foff[it][c] = epx * kFramePS + epx + ky * 12 + kx;
+                t.v[lane][4 * it + c] = (unsigned short)(4 * (epx * kFramePS + epx + ky * 12 + kx));
             }
         }
+    return t;
+}
+__device__ const FoffTable kFoffTable = make_foff_table();
+
+__device__ __forceinline__ uint4 load_foff(int lane) {
+    return *reinterpret_cast<const uint4*>(&kFoffTable.v[lane][0]);
+}
+
+// `tab` = load_foff(lane), fetched by the caller long before the epilogue.
+template <typename T>
+__device__ __forceinline__ void store_tile(const float* fr, T* ob, int lane, int x0, int y0, int H,
+                                           int W, int out_pix_stride, float slope, float inv_c,
+                                           float cf, uint4 tab) {
+    const int row_stride = W * out_pix_stride;
+    if (out_pix_stride == 81 && (W & 3) == 0 && x0 + 4 <= W && y0 + 4 <= H &&
+        (reinterpret_cast<uintptr_t>(ob) & (4 * sizeof(T) - 1)) == 0) {  // wave-uniform
+        // lane owns elements 4*q .. 4*q+3 of the 324-float row, q = lane (+64 for lanes 0..16)
+        const unsigned tw[4] = {tab.x, tab.y, tab.z, tab.w};
+        const char* frb = reinterpret_cast<const char*>(fr);
         float v[4][2][4];
 #pragma unroll
         for (int row = 0; row < 4; ++row)
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[row][it][c] = fr[foff[it][c] + row * kRowStep];
-        const bool second = lane < 17;  // float4 64..80
-#pragma unroll
-        for (int row = 0; row < 4; ++row) {
-            T* orow = ob + (int64_t)row * row_stride;
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                float4 o;
-                if (inv_c > 0.f) {
-                    o = make_float4(lrelu(v[row][it][0] * inv_c, slope), lrelu(v[row][it][1] * inv_c, slope),
-                                    lrelu(v[row][it][2] * inv_c, slope), lrelu(v[row][it][3] * inv_c, slope));
-                } else {
-                    o = make_float4(lrelu(v[row][it][0] / cf, slope), lrelu(v[row][it][1] / cf, slope),
-                                    lrelu(v[row][it][2] / cf, slope), lrelu(v[row][it][3] / cf, slope));
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned w = tw[2 * it + (c >> 1)];
+                    const unsigned off = (c & 1) ? (w >> 16) : (w & 0xffffu);
+                    v[row][it][c] = *reinterpret_cast<const float*>(frb + off + row * (kRowStep * 4));
                 }
-                if (it == 0 || second) st4(orow + 4 * (lane + 64 * it), o);
+        const bool second = lane < 17;  // float4 64..80
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        auto emit = [&](auto act) {
+#pragma unroll
+            for (int row = 0; row < 4; ++row) {
+                T* orow = ob + (int64_t)row * row_stride;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const float4 o = act(v[row][it]);
+                    if (it == 0 || second) st4(orow + 4 * (lane + 64 * it), o);
+                }
             }
+        };
+        // mean then LeakyReLU.  For 0 <= slope <= 1 and an exact 1/C (power of two),
+        // lrelu(v/C) == max(v*(1/C), v*(slope/C)) bit for bit: two packed multiplies and a max
+        // instead of multiply, compare, multiply, select.
+        if (inv_c > 0.f && slope >= 0.f && slope <= 1.f) {  // wave-uniform
+            const float k1 = inv_c, k2 = inv_c * slope;
+            emit([&](const float* x) {
+                const f32x2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
+                const f32x2 a0 = lo * k1, b0 = lo * k2, a1 = hi * k1, b1 = hi * k2;
+                return make_float4(fmaxf(a0.x, b0.x), fmaxf(a0.y, b0.y), fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y));
+            });
+        } else if (inv_c > 0.f) {
+            emit([&](const float* x) {
+                return make_float4(lrelu(x[0] * inv_c, slope), lrelu(x[1] * inv_c, slope),
+                                   lrelu(x[2] * inv_c, slope), lrelu(x[3] * inv_c, slope));
+            });
+        } else {
+            emit([&](const float* x) {
+                return make_float4(lrelu(x[0] / cf, slope), lrelu(x[1] / cf, slope), lrelu(x[2] / cf, slope),
+                                   lrelu(x[3] / cf, slope));
+            });
         }
         return;
     }
@@ -324,6 +365,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void cost_volume_mfma_kernel(
     const float cf = (float)C;
     const float* f0 = frames + grp * KS * kFrameFloats;
     T* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;  // scalar
+    if (KS == 1) {  // the wave owns the whole frame: batched reads, 16-byte stores where possible
+        store_tile<T>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, cf, load_foff(lane));
+        return;
+    }
     const int row_stride = W * out_pix_stride;
     const bool use_mul = inv_c > 0.f;  // wave-uniform
     const float scale = use_mul ? inv_c : cf;
@@ -369,14 +414,32 @@ constexpr int kRegBlocks = 20;                       // 16 nxt + 4 prv
 constexpr int kRegStageBytes = kRegBlocks * 2048;    // 32 channels fp32 per step
 constexpr int kRegLdsBytes = kRegStageBytes > 4 * kFrameFloats * 4 ? kRegStageBytes : 4 * kFrameFloats * 4;
 
+template <bool PERSIST>
 __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     const float* __restrict__ prv, const float* __restrict__ nxt, float* __restrict__ out, int H, int W,
-    int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c) {
+    int C, int regs_x, int regs_y, int n_regions, int out_pix_stride, float slope, float inv_c,
+    int stagger_mode, int stagger_delta) {
     __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytes];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Every workgroup of the first resident round starts at the same instant and the three phases
+    // (load / matrix cores / store) are each chip-wide bandwidth bound, so the whole grid marches in
+    // lock step and the phase times ADD.  Delaying the co-resident workgroups of a CU by different
+    // amounts puts them in different phases; later rounds inherit the offsets.
+    if (stagger_mode && blockIdx.x < 1024u) {
+        int slot;
+        if (stagger_mode == 1) slot = (blockIdx.x >> 8) & 3;
+        else if (stagger_mode == 2) slot = (blockIdx.x >> 3) & 3;
+        else slot = __builtin_amdgcn_s_getreg((0 << 0) | (4 << 6) | ((4 - 1) << 11)) & 3;  // HW_ID.wave_id
+        for (int i = 0; i < slot * stagger_delta; ++i) __builtin_amdgcn_s_sleep(16);  // 16*64 cycles
+    }
+    // PERSIST: a resident workgroup walks regions vid = blockIdx.x, + gridDim.x, ... (gridDim.x is a
+    // multiple of 8, so a workgroup stays on the run of regions that belongs to its XCD)
+    for (int vid = blockIdx.x; vid < n_regions; vid += gridDim.x) {
+    if (PERSIST && vid != (int)blockIdx.x) __syncthreads();  // frames of the previous region are read
+    int tid = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(tid));  // recompute the lane maps per region: hoisted, they spill
     const int lane = tid & 63;
-    const int region = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int region = xcd_swizzle(vid, n_regions);
     const int rx = region % regs_x, ry = (region / regs_x) % regs_y, b = region / (regs_x * regs_y);
     const int X0 = rx * 8, Y0 = ry * 8;
 
@@ -390,21 +453,25 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     const int hi = tid >> 7, within = tid & 127, sn = within >> 3, sc = within & 7;
     const int spy = sn >> 2, spx = sn & 3;
     const int lds_w = hi * 2048 + sn * 128 + ((sc ^ (sn >> 1)) << 4);  // + it*4096
+    // byte offsets inside image b, 32-bit modular arithmetic: a row above the image gives a
+    // "negative" = huge unsigned offset, which the descriptor turns into zeros like a row below
     unsigned goff[10];
+    {
+        const unsigned pix = (unsigned)C * 4u;                       // bytes per pixel (scalar)
+        const unsigned rowb = (unsigned)W * pix;                     // bytes per image row (scalar)
+        const int xn = X0 - 4 + 4 * hi + spx;                        // column for even `it` (bj = hi)
+        const unsigned base_n = (unsigned)(Y0 - 4 + spy) * rowb + (unsigned)xn * pix + (unsigned)sc * 16u;
+        const bool ok0 = xn >= 0 && xn < W, ok1 = xn + 8 >= 0 && xn + 8 < W;   // bj = hi, hi + 2
 #pragma unroll
-    for (int it = 0; it < 10; ++it) {
-        int y, x;
-        if (it < 8) {  // nxt block (bi, bj) of the 4x4 block grid at (Y0-4, X0-4)
-            const int bi = it >> 1, bj = 2 * (it & 1) + hi;
-            y = Y0 - 4 + 4 * bi + spy;
-            x = X0 - 4 + 4 * bj + spx;
-        } else {       // prv tile (ti, tj)
-            const int ti = it - 8, tj = hi;
-            y = Y0 + 4 * ti + spy;
-            x = X0 + 4 * tj + spx;
+        for (int it = 0; it < 8; ++it) {  // nxt block (bi, bj) = (it >> 1, 2 * (it & 1) + hi)
+            const unsigned o = base_n + (unsigned)(it >> 1) * 4u * rowb + (unsigned)(it & 1) * 8u * pix;
+            goff[it] = ((it & 1) ? ok1 : ok0) ? o : kOob;
         }
-        const bool col_ok = x >= 0 && x < W;  // rows outside the image fall out of the descriptor
-        goff[it] = col_ok ? (unsigned)((y * W + x) * C * 4 + sc * 16) : kOob;
+        const int xp = X0 + 4 * hi + spx;                            // prv tile (ti, tj) = (it - 8, hi)
+        const unsigned base_p = (unsigned)(Y0 + spy) * rowb + (unsigned)xp * pix + (unsigned)sc * 16u;
+        const bool okp = xp < W;
+        goff[8] = okp ? base_p : kOob;
+        goff[9] = okp ? base_p + 4u * rowb : kOob;
     }
 
     // ---- operand map (matrix-core layout): lane = pixel n, k-slot g ------------
@@ -413,23 +480,23 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     const int lds_r = n * 128;  // + block*2048 + ((4u+g) ^ (n>>1))*16
     const int sw = n >> 1;
 
+    uint4 tab = load_foff(lane);  // epilogue offsets: in flight behind the first staging loads
     f32x4 acc[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int nsteps = C / 32;
-    for (int s = 0; s < nsteps; ++s) {
+    // one 32-channel step; FIRST: the accumulators start from the instruction's zero operand
+    // (no 36 register clears) and the offset table is pinned once the staging loads have landed
+    auto step = [&](int s, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         const int soff = s * 128;
         u32x4 st[10];
 #pragma unroll
         for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
 #pragma unroll
         for (int it = 8; it < 10; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[it], soff, 0);
-        if (s > 0) __syncthreads();  // previous step's operand reads are done
+        if (!FIRST) __syncthreads();  // previous step's operand reads are done
 #pragma unroll
         for (int it = 0; it < 10; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = st[it];
+        if (FIRST) asm volatile("" : "+v"(tab.x), "+v"(tab.y), "+v"(tab.z), "+v"(tab.w));
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -446,10 +513,14 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nv[i][j][t], pv[t], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 3; ++j) {
+                        const f32x4 c0 = (FIRST && u == 0 && t == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nv[i][j][t], pv[t], c0, 0, 0, 0);
+                    }
         }
-    }
+    };
+    step(0, std::true_type{});
+    for (int s = 1; s < nsteps; ++s) step(s, std::false_type{});
     __syncthreads();  // staging area becomes the four output frames
 
     float* fr = reinterpret_cast<float*>(smem) + wave * kFrameFloats;
@@ -463,9 +534,12 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     __builtin_amdgcn_wave_barrier();
 
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
-    if (x0 >= W || y0 >= H) return;
-    float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
-    store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C);
+    if (x0 < W && y0 < H) {
+        float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
+        store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab);
+    }
+    if (!PERSIST) break;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -524,6 +598,7 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    uint4 tab = load_foff(lane);  // epilogue offsets, fetched early
     const int nsteps = C / 32;
     for (int s = 0; s < nsteps; ++s) {
         const int soff = s * 64;
@@ -559,7 +634,7 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
     if (x0 >= W || y0 >= H) return;
     __half* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
-    store_tile<__half>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C);
+    store_tile<__half>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab);
 }
 
 static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int B, int H, int W, int C,
@@ -596,8 +671,24 @@ static int launch_lds(const float* prv, const float* nxt, float* out, int B, int
         return QPWC_E_SHAPE;
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
-    hipLaunchKernelGGL(cost_volume_mfma_lds_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
-                       H, W, C, regs_x, regs_y, (int)ops, slope, inv_c);
+    static const int persist = [] {
+        const char* e = getenv("QPWC_CV_PERSIST");  // resident workgroups per CU (A/B measurements)
+        return e ? atoi(e) : 0;
+    }();
+    static int st_mode = 0, st_delta = 0;
+    static const bool st_init = [] {
+        const char* e = getenv("QPWC_CV_STAGGER");  // "mode,delta" (A/B measurements)
+        if (e) sscanf(e, "%d,%d", &st_mode, &st_delta);
+        return true;
+    }();
+    (void)st_init;
+    if (persist > 0 && nblk > 256 * persist) {
+        hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<true>, dim3(256u * persist), dim3(256), 0, s, prv, nxt,
+                           out, H, W, C, regs_x, regs_y, (int)nblk, (int)ops, slope, inv_c, st_mode, st_delta);
+        return check_launch("cost_volume_mfma_lds_kernel<persist>");
+    }
+    hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
+                       H, W, C, regs_x, regs_y, (int)nblk, (int)ops, slope, inv_c, st_mode, st_delta);
     return check_launch("cost_volume_mfma_lds_kernel");
 }
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""A/B helper: checks the cost volume at the L3/L4 shapes against the generic kernel path
+(QPWC_CV_IMPL is read once per process, so the reference comes from the C ABI with a search-range
+trick-free call on a crop) -- here simply against torch, then times it.  Env switches are read by
+the library at first use."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qpwcnet_amd import ops
+
+def ref(prv, nxt):
+    B, H, W, C = prv.shape
+    pad = torch.nn.functional.pad(nxt, (0, 0, 4, 4, 4, 4))
+    outs = []
+    for i in range(9):
+        for j in range(9):
+            outs.append((prv * pad[:, i:i + H, j:j + W]).mean(-1, keepdim=True))
+    return torch.nn.functional.leaky_relu(torch.cat(outs, -1), 0.1)
+
+g = torch.Generator(device="cuda").manual_seed(0)
+for shape in [(8, 128, 256, 32), (8, 64, 128, 64), (3, 52, 76, 32)]:
+    prv = torch.randn(*shape, device="cuda", generator=g); nxt = torch.randn(*shape, device="cuda", generator=g)
+    got = ops.cost_volume(prv, nxt)
+    err = float((got - ref(prv, nxt)).abs().max())
+    for _ in range(5): ops.cost_volume(prv, nxt)
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50): ops.cost_volume(prv, nxt)
+        e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / 50 * 1e3)
+    print(shape, "max err %.2e" % err, "us med %.2f min %.2f" % (sorted(ts)[2], min(ts)), flush=True)
