@@ -77,8 +77,9 @@ __device__ __forceinline__ uint4 load_foff(int lane) {
 }
 
 // `tab` = load_foff(lane), fetched by the caller long before the epilogue.
+// Returns true when the dense path ran (exactly 8 store instructions per wave).
 template <typename T>
-__device__ __forceinline__ void store_tile(const float* fr, T* ob, int lane, int x0, int y0, int H,
+__device__ __forceinline__ bool store_tile(const float* fr, T* ob, int lane, int x0, int y0, int H,
                                            int W, int out_pix_stride, float slope, float inv_c,
                                            float cf, uint4 tab) {
     const int row_stride = W * out_pix_stride;
@@ -132,7 +133,7 @@ __device__ __forceinline__ void store_tile(const float* fr, T* ob, int lane, int
                                    lrelu(x[3] / cf, slope));
             });
         }
-        return;
+        return true;
     }
     // general case: strided output (concat buffer), ragged image edge
     int foff[6];
@@ -163,6 +164,7 @@ __device__ __forceinline__ void store_tile(const float* fr, T* ob, int lane, int
             if ((s < 5 || tail) && y0 + row < H && x0 + epx[s] < W) st(orow + goff[s], lrelu(m, slope));
         }
     }
+    return false;
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -414,32 +416,14 @@ constexpr int kRegBlocks = 20;                       // 16 nxt + 4 prv
 constexpr int kRegStageBytes = kRegBlocks * 2048;    // 32 channels fp32 per step
 constexpr int kRegLdsBytes = kRegStageBytes > 4 * kFrameFloats * 4 ? kRegStageBytes : 4 * kFrameFloats * 4;
 
-template <bool PERSIST>
 __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     const float* __restrict__ prv, const float* __restrict__ nxt, float* __restrict__ out, int H, int W,
-    int C, int regs_x, int regs_y, int n_regions, int out_pix_stride, float slope, float inv_c,
-    int stagger_mode, int stagger_delta) {
+    int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c) {
     __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytes];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Every workgroup of the first resident round starts at the same instant and the three phases
-    // (load / matrix cores / store) are each chip-wide bandwidth bound, so the whole grid marches in
-    // lock step and the phase times ADD.  Delaying the co-resident workgroups of a CU by different
-    // amounts puts them in different phases; later rounds inherit the offsets.
-    if (stagger_mode && blockIdx.x < 1024u) {
-        int slot;
-        if (stagger_mode == 1) slot = (blockIdx.x >> 8) & 3;
-        else if (stagger_mode == 2) slot = (blockIdx.x >> 3) & 3;
-        else slot = __builtin_amdgcn_s_getreg((0 << 0) | (4 << 6) | ((4 - 1) << 11)) & 3;  // HW_ID.wave_id
-        for (int i = 0; i < slot * stagger_delta; ++i) __builtin_amdgcn_s_sleep(16);  // 16*64 cycles
-    }
-    // PERSIST: a resident workgroup walks regions vid = blockIdx.x, + gridDim.x, ... (gridDim.x is a
-    // multiple of 8, so a workgroup stays on the run of regions that belongs to its XCD)
-    for (int vid = blockIdx.x; vid < n_regions; vid += gridDim.x) {
-    if (PERSIST && vid != (int)blockIdx.x) __syncthreads();  // frames of the previous region are read
-    int tid = threadIdx.x;
-    if (PERSIST) asm volatile("" : "+v"(tid));  // recompute the lane maps per region: hoisted, they spill
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int region = xcd_swizzle(vid, n_regions);
+    const int region = xcd_swizzle(blockIdx.x, gridDim.x);
     const int rx = region % regs_x, ry = (region / regs_x) % regs_y, b = region / (regs_x * regs_y);
     const int X0 = rx * 8, Y0 = ry * 8;
 
@@ -534,12 +518,9 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     __builtin_amdgcn_wave_barrier();
 
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
-    if (x0 < W && y0 < H) {
-        float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
-        store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab);
-    }
-    if (!PERSIST) break;
-    }
+    if (x0 >= W || y0 >= H) return;
+    float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
+    store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab);
 }
 
 // ---------------------------------------------------------------------------
@@ -652,6 +633,11 @@ static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int
     return check_launch("cost_volume_mfma_lds_f16_kernel");
 }
 
+
+#ifdef QPWC_EXPERIMENTAL
+#include "experimental/cost_volume_pipe.inc"
+#endif
+
 // QPWC_CV_LDS=0 keeps every shape on the per-wave split-K kernel (A/B measurements only).
 static int lds_mode() {
     static const int v = [] {
@@ -671,24 +657,14 @@ static int launch_lds(const float* prv, const float* nxt, float* out, int B, int
         return QPWC_E_SHAPE;
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
-    static const int persist = [] {
-        const char* e = getenv("QPWC_CV_PERSIST");  // resident workgroups per CU (A/B measurements)
-        return e ? atoi(e) : 0;
-    }();
-    static int st_mode = 0, st_delta = 0;
-    static const bool st_init = [] {
-        const char* e = getenv("QPWC_CV_STAGGER");  // "mode,delta" (A/B measurements)
-        if (e) sscanf(e, "%d,%d", &st_mode, &st_delta);
-        return true;
-    }();
-    (void)st_init;
-    if (persist > 0 && nblk > 256 * persist) {
-        hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<true>, dim3(256u * persist), dim3(256), 0, s, prv, nxt,
-                           out, H, W, C, regs_x, regs_y, (int)nblk, (int)ops, slope, inv_c, st_mode, st_delta);
-        return check_launch("cost_volume_mfma_lds_kernel<persist>");
+#ifdef QPWC_EXPERIMENTAL
+    {
+        const int rc = launch_experimental(prv, nxt, out, H, W, C, regs_x, regs_y, nblk, ops, slope, inv_c, s);
+        if (rc <= 0) return rc;
     }
-    hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
-                       H, W, C, regs_x, regs_y, (int)nblk, (int)ops, slope, inv_c, st_mode, st_delta);
+#endif
+    hipLaunchKernelGGL(cost_volume_mfma_lds_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
+                       H, W, C, regs_x, regs_y, (int)ops, slope, inv_c);
     return check_launch("cost_volume_mfma_lds_kernel");
 }
 
@@ -760,3 +736,7 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
 }
 
 }  // namespace qpwc
+
+#if defined(QPWC_EXPERIMENTAL) && defined(QPWC_STAMP)
+#include "experimental/debug_exports.inc"
+#endif

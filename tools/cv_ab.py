@@ -29,3 +29,17 @@ for shape in [(8, 128, 256, 32), (8, 64, 128, 64), (3, 52, 76, 32)]:
         for _ in range(50): ops.cost_volume(prv, nxt)
         e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / 50 * 1e3)
     print(shape, "max err %.2e" % err, "us med %.2f min %.2f" % (sorted(ts)[2], min(ts)), flush=True)
+
+if os.environ.get("QPWC_STAMPS"):
+    import ctypes
+    from qpwcnet_amd import _hip
+    L = _hip.lib()
+    prv = torch.randn(8, 128, 256, 32, device="cuda"); nxt = torch.randn(8, 128, 256, 32, device="cuda")
+    ops.cost_volume(prv, nxt); torch.cuda.synchronize()
+    buf = (ctypes.c_uint64 * 96)()
+    L.qpwc_debug_stamps.argtypes = [ctypes.c_void_p]
+    print("rc", L.qpwc_debug_stamps(buf))
+    names = [["A wait", "reads+mfma", "B wait", "frame write"], ["vmcnt+A wait", "dma issue", "epilogue", "B wait"]]
+    for w in range(12):
+        print("wave", w, "matrix" if w < 4 else ("loader" if w < 8 else "storer"),
+              "  ".join("%s %d" % (names[w >= 4][k], buf[w * 8 + k]) for k in range(4)))
