@@ -28,23 +28,42 @@ __global__ __launch_bounds__(256) void warp_nhwc_vec4_kernel(const T* __restrict
                                                              int W, int C, FloStrides fs) {
     const int nch = C >> 2;
     const int64_t total = (int64_t)B * H * W * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = idx % nch;
-        int64_t p = idx / nch;
-        const int x = p % W;
-        p /= W;
-        const int y = p % H;
-        const int b = p / H;
-        const float* f = flo + b * fs.b + y * fs.y + x * fs.x;
-        const float fx = f[0], fy = f[fs.c];
-        const Taps t = make_taps<MODE>(y, x, fx, fy, H, W);
-        const T* ib = img + (int64_t)b * H * W * C + 4 * ch;
-        const float4 tl = ld4(ib + ((int64_t)t.y0 * W + t.x0) * C);
-        const float4 tr = ld4(ib + ((int64_t)t.y0 * W + t.x1) * C);
-        const float4 bl = ld4(ib + ((int64_t)t.y1 * W + t.x0) * C);
-        const float4 br = ld4(ib + ((int64_t)t.y1 * W + t.x1) * C);
-        st4(out + (((int64_t)(b * H + y) * W + x) * C + 4 * ch), blend4<MODE>(t, tl, tr, bl, br));
+    // two independent items per thread and trip: 2 flow reads, then 8 corner gathers in flight
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx0 < total; idx0 += 2 * stride) {
+        const int64_t idx1 = idx0 + stride;
+        const bool two = idx1 < total;
+        int ch[2], x[2], y[2], b[2];
+        float fx[2], fy[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t idx = (k == 0 || two) ? (k == 0 ? idx0 : idx1) : idx0;
+            ch[k] = idx % nch;
+            int64_t p = idx / nch;
+            x[k] = p % W;
+            p /= W;
+            y[k] = p % H;
+            b[k] = p / H;
+            const float* f = flo + b[k] * fs.b + y[k] * fs.y + x[k] * fs.x;
+            fx[k] = f[0];
+            fy[k] = f[fs.c];
+        }
+        float4 tl[2], tr[2], bl[2], br[2];
+        Taps t[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            t[k] = make_taps<MODE>(y[k], x[k], fx[k], fy[k], H, W);
+            const T* ib = img + (int64_t)b[k] * H * W * C + 4 * ch[k];
+            tl[k] = ld4(ib + ((int64_t)t[k].y0 * W + t[k].x0) * C);
+            tr[k] = ld4(ib + ((int64_t)t[k].y0 * W + t[k].x1) * C);
+            bl[k] = ld4(ib + ((int64_t)t[k].y1 * W + t[k].x0) * C);
+            br[k] = ld4(ib + ((int64_t)t[k].y1 * W + t[k].x1) * C);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k == 0 || two)
+                st4(out + (((int64_t)(b[k] * H + y[k]) * W + x[k]) * C + 4 * ch[k]),
+                    blend4<MODE>(t[k], tl[k], tr[k], bl[k], br[k]));
     }
 }
 
@@ -99,7 +118,8 @@ static int warp_impl(const T* img, const float* flo, T* out, int B, int H, int W
                       reinterpret_cast<uintptr_t>(img) % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(out) % 16 == 0;
     const int64_t total = fast ? (int64_t)B * H * W * (C / 4) : (int64_t)B * H * W * C;
-    const int64_t want = (total + 255) / 256;
+    // fast path: two items per thread; every CU gets >= 8 workgroups before the grid is halved
+    const int64_t want = fast && total >= 2 * 256 * 2048 ? (total + 511) / 512 : (total + 255) / 256;
     const unsigned grid = (unsigned)(want < (1 << 20) ? want : (1 << 20));
     if (fast)
         hipLaunchKernelGGL((warp_nhwc_vec4_kernel<T, MODE>), dim3(grid), dim3(256), 0, s, img, flo,

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--levels", default="0,1,2,3,4")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--no-graph", action="store_true",
+                    help="time eager launches (host-bound below ~12 us) instead of a hipGraph of `iters` launches")
     a = ap.parse_args()
     H0, W0 = map(int, a.res.split("x"))
     chans = [256, 256, 128, 64, 32]
@@ -62,12 +64,26 @@ def main():
         for _ in range(3):
             fn()
     torch.cuda.synchronize()
+    graphs = {}
+    if not a.no_graph:  # `iters` back-to-back launches per case as one hipGraph: no host launch gaps
+        side = torch.cuda.Stream()
+        for name, fn, _ in cases:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(a.iters):
+                        fn()
+            graphs[name] = g
+        torch.cuda.synchronize()
     for _ in range(a.rounds):
         for name, fn, _ in cases:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(a.iters):
-                fn()
+            if name in graphs:
+                graphs[name].replay()
+            else:
+                for _ in range(a.iters):
+                    fn()
             e1.record()
             e1.synchronize()
             times[name].append(e0.elapsed_time(e1) / a.iters * 1e3)  # us
