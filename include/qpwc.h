@@ -143,7 +143,7 @@ int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
  *   out[b,y,x,f] = bias[f] + sum_c pw[f,c] * (depthwise3x3(in0))[b,y,x,c]
  * with `in`/`in0` as in qpwc_dwconv3x3_fwd (1..3 sources, optional Mish on load); the
  * depthwise result stays on chip (LDS -> matrix cores).  dw: (C,3,3); pw: (F, Cpad) row-major,
- * Cpad = ceil(C/16)*16, zero padded; bias: (F); F in {16,32,64,128}; out: (B,H,W,F) dense. */
+ * Cpad = ceil(C/32)*32, zero padded; bias: (F); F in {16,32,64,128}; out: (B,H,W,F) dense. */
 int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
                         const int64_t* src_pixel_stride, int n_src, int mish_on_load,
                         const void* dw, const void* pw, const void* bias, void* out,

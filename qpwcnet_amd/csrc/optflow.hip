@@ -291,130 +291,243 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
 
 // ---------------------------------------------------------------------------
 // sepconv3x3_fused: the WHOLE SeparableConv2D (depthwise 3x3 -> pointwise 1x1 + bias,
-// pre-activation output) in one launch, fp32.  The depthwise result never goes to HBM:
-// per 16-channel chunk a workgroup (4 waves, 8x8 pixel tile) stages the 10x10 halo tile
-// of the (virtually concatenated, optionally Mish-activated) input in LDS, computes the
-// depthwise outputs into an LDS operand tile, and feeds them with the matching slice of
-// the pointwise weights to v_mfma_f32_16x16x4_f32 (rows = output channels, cols = the
-// wave's 16 pixels).  k-slot g of a lane owns channels 4g..4g+3 of the chunk, so every
-// operand is one ds_read_b128.
-// pointwise weights: (F, Cpad) row-major with Cpad = ceil(C/16)*16, zero padded.
-constexpr int kScKC = 16;               // channels per chunk
-constexpr int kScTile = 8;              // 8x8 pixels per workgroup
-constexpr int kScHalo = kScTile + 2;
-constexpr int kScLd = 20;               // padded row stride (floats) of the operand tiles
+// pre-activation output) in one launch, fp32 (non_layers.py:223-231).  The depthwise result
+// never goes to HBM: input read once (+27..41 % halo), output written once.
+//
+// Workgroup = 4 waves = an 8 x 16 pixel tile; channels in steps of 32:
+//   stage   : the 10 x 18 halo tile of the (virtually concatenated, optionally Mish-activated)
+//             input, 32 channels, global -> registers (prefetched one step ahead) -> LDS
+//             `in_s` (pixel stride 40 floats: the depthwise b128 reads are conflict free);
+//             the 32 x F slice of the pointwise weights -> `w_s`, the 32 x 9 depthwise taps -> `dw_s`;
+//   depthw. : thread = (4 consecutive pixels, 4 channels): 18 ds_read_b128, 144 FMA, the result
+//             -> `y_s` [128 px][32 ch] as 4 ds_write_b128;
+//   pointw. : v_mfma_f32_16x16x4_f32, rows = output channels (A = w_s), cols = pixels (B = y_s);
+//             a wave owns 32 pixels x all F outputs (2 x F/16 accumulators); per 16 channels it
+//             reads 2 + F/16 operands (ds_read_b128: k-slot g of a lane owns channels 4g..4g+3)
+//             for 8 x F/16 matrix instructions.  `y_s` / `w_s` rows are 128 B with the 16-byte
+//             chunk c of row n at chunk c ^ (n >> 1) (conflict free, as in the cost volume).
+// 62 KB LDS -> 2 workgroups per CU: while one is in its matrix phase the other stages/convolves.
+// pointwise weights: (F, Cpad) row-major with Cpad = ceil(C/32)*32, zero padded.
+constexpr int kScKC = 32;               // channels per step
+constexpr int kScTH = 8, kScTW = 16;    // pixel tile
+constexpr int kScHH = kScTH + 2, kScHW = kScTW + 2;
+constexpr int kScNH = kScHH * kScHW;    // 180 halo pixels
+constexpr int kScInPS = 40;             // floats per halo pixel in in_s
 
-template <int F, bool ACT>
-__global__ __launch_bounds__(256) void sepconv3x3_fused_kernel(
+template <int F, bool ACT, bool VEC>
+__global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     DwSrc src, const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y) {
     constexpr int NFT = F / 16;
-    __shared__ __attribute__((aligned(16))) float in_s[kScHalo * kScHalo * kScKC];
-    __shared__ __attribute__((aligned(16))) float y_s[64 * kScLd];
-    __shared__ __attribute__((aligned(16))) float w_s[F * kScLd];
+    constexpr int NST = VEC ? 6 : 23;   // staging loads per thread and step
+    __shared__ __attribute__((aligned(16))) float in_s[kScNH * kScInPS];
+    __shared__ __attribute__((aligned(16))) float y_s[kScTH * kScTW * kScKC];
+    __shared__ __attribute__((aligned(16))) float w_s[F * kScKC];
+    __shared__ __attribute__((aligned(16))) float dw_s[9 * kScKC];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int tile = blockIdx.x;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int X0 = tx * kScTile, Y0 = ty * kScTile;
+    const int X0 = tx * kScTW, Y0 = ty * kScTH;
     const int n = lane & 15, g = lane >> 4;
 
-    f32x4v acc[NFT];
+    f32x4v acc[2][NFT];
 #pragma unroll
-    for (int i = 0; i < NFT; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < NFT; ++i) acc[m][i] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    const int dc = tid & 15;       // channel of this thread inside a chunk (staging + depthwise)
-    const int dp = tid >> 4;       // 0..15
-    for (int c0 = 0; c0 < cpad; c0 += kScKC) {
-        // ---- stage the halo tile of this chunk (Mish applied once per element) ---------
-        const int c = c0 + dc;
-        const float* p = nullptr;
-        int64_t ps = 0;
-        if (c < C) {
-            int cc;
-            if (c < src.ch[0]) {
-                p = (const float*)src.ptr[0]; ps = src.stride[0]; cc = c;
-            } else if (c < src.ch[0] + src.ch[1]) {
-                p = (const float*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
-            } else {
-                p = (const float*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
-            }
-            p += (int64_t)b * H * W * ps + cc;
-        }
+    // ---- staging map --------------------------------------------------------------
+    // generic: lane = channel (32 lanes = 128 contiguous bytes of one pixel), 8 halo pixels per trip
+    // VEC    : 8 lanes x 16 B per pixel, 32 halo pixels per trip (one dense 16-byte-aligned source)
+    const int sch = VEC ? 4 * (tid & 7) : (tid & 31);
+    const int sps = VEC ? (tid >> 3) : (tid >> 5);
+    constexpr int SPT = VEC ? 32 : 8;
+    int goff[NST];       // pixel offset of halo pixel `it` inside image b (-1 = outside; H*W < 2^31)
 #pragma unroll
-        for (int it = 0; it < 7; ++it) {
-            const int hp = dp + 16 * it;  // halo pixel 0..99
-            if (hp < kScHalo * kScHalo) {
-                const int hy = hp / kScHalo, hx = hp - hy * kScHalo;
-                const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
-                float v = 0.0f;
-                if (p && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    v = p[((int64_t)gy * W + gx) * ps];
-                    if (ACT) v = mishf(v);
-                }
-                in_s[hp * kScKC + dc] = v;
-            }
-        }
-        // pointwise weights of this chunk: w_s[f][0..15] = pw[f][c0..c0+15]
-        for (int i = tid; i < F * 4; i += 256) {
-            const int f = i >> 2, q = i & 3;
-            *reinterpret_cast<float4*>(w_s + f * kScLd + 4 * q) =
-                *reinterpret_cast<const float4*>(pw + (int64_t)f * cpad + c0 + 4 * q);
-        }
-        float wk[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = c < C ? dw[c * 9 + k] : 0.0f;
-        __syncthreads();
-        // ---- depthwise: 4 pixels per thread for channel dc ----------------------------
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pix = dp + 16 * j;  // 0..63
-            const int py = pix >> 3, px = pix & 7;
-            float a = 0.0f;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-                    a = fmaf(wk[ky * 3 + kx], in_s[((py + ky) * kScHalo + px + kx) * kScKC + dc], a);
-            y_s[pix * kScLd + dc] = a;
-        }
-        __syncthreads();
-        // ---- pointwise on the matrix cores: D[f][px] += W[f][k] * y[px][k] --------------
-        const f32x4v yv = *reinterpret_cast<const f32x4v*>(y_s + (16 * wave + n) * kScLd + 4 * g);
-#pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) {
-            const f32x4v wv = *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScLd + 4 * g);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], yv[t], acc[ft], 0, 0, 0);
-        }
-        __syncthreads();  // operand tiles are rewritten by the next chunk
+    for (int it = 0; it < NST; ++it) {
+        const int hp = sps + SPT * it;
+        const int hy = hp / kScHW, hx = hp - hy * kScHW;
+        const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+        goff[it] = (hp < kScNH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
     }
-    // ---- bias + store: lane = pixel n of the wave's 16, 4 consecutive outputs 4g..4g+3 ----
-    const int pix = 16 * wave + n;
-    const int gy = Y0 + (pix >> 3), gx = X0 + (pix & 7);
-    if (gy < H && gx < W) {
-        float* o = out + ((int64_t)(b * H + gy) * W + gx) * F;
+    float4 st4[VEC ? NST : 1];
+    float4 wreg0, wreg1, wreg2, wreg3;   // F/32 of them in use (kept out of an array: no LDS promotion)
+    float dreg[2];
+    wreg0 = wreg1 = wreg2 = wreg3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int c0) {   // global -> registers for the step starting at channel c0
+        const int c = c0 + sch;
+        if (VEC) {
+            const float* p = (const float*)src.ptr[0] + (int64_t)b * H * W * src.stride[0] + c;
 #pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
-            *reinterpret_cast<float4*>(o + 16 * ft + 4 * g) =
-                make_float4(acc[ft][0] + bv.x, acc[ft][1] + bv.y, acc[ft][2] + bv.z, acc[ft][3] + bv.w);
+            for (int it = 0; it < NST; ++it)
+                st4[it] = (goff[it] >= 0 && c < C) ? *reinterpret_cast<const float4*>(p + (int64_t)goff[it] * src.stride[0])
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // (the generic multi-source path loads its inputs in commit(): 23 more live registers across
+        // the depthwise and matrix phases would spill; the other workgroup of the CU covers the latency)
+        {   // pointwise slice: F rows x 8 chunks of 16 B, 256 chunks per trip
+            const float* wp = pw + (int64_t)(tid >> 3) * cpad + c0 + 4 * (tid & 7);
+            if (F >= 32 || (tid >> 3) < F) wreg0 = *reinterpret_cast<const float4*>(wp);
+            if (F >= 64) wreg1 = *reinterpret_cast<const float4*>(wp + (int64_t)32 * cpad);
+            if (F >= 128) {
+                wreg2 = *reinterpret_cast<const float4*>(wp + (int64_t)64 * cpad);
+                wreg3 = *reinterpret_cast<const float4*>(wp + (int64_t)96 * cpad);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {        // depthwise taps of the 32 channels: 288 floats
+            const int idx = tid + 256 * i;
+            dreg[i] = (idx < kScKC * 9 && c0 * 9 + idx < C * 9) ? dw[c0 * 9 + idx] : 0.0f;
+        }
+    };
+    auto commit = [&](int c0) {  // registers -> LDS
+        if (VEC) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int hp = sps + SPT * it;
+                if (hp < kScNH) {
+                    float4 v = st4[it];
+                    if (ACT && goff[it] >= 0) v = make_float4(mishf(v.x), mishf(v.y), mishf(v.z), mishf(v.w));
+                    *reinterpret_cast<float4*>(in_s + hp * kScInPS + sch) = v;
+                }
+            }
+        } else {
+            const int c = c0 + sch;
+            const float* p = nullptr;
+            int64_t ps = 0;
+            if (c < C) {
+                int cc;
+                if (c < src.ch[0]) {
+                    p = (const float*)src.ptr[0]; ps = src.stride[0]; cc = c;
+                } else if (c < src.ch[0] + src.ch[1]) {
+                    p = (const float*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
+                } else {
+                    p = (const float*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
+                }
+                p += (int64_t)b * H * W * ps + cc;
+            }
+            float st[NST];
+#pragma unroll
+            for (int it = 0; it < NST; ++it) st[it] = (p && goff[it] >= 0) ? p[(int64_t)goff[it] * ps] : 0.0f;
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int hp = sps + SPT * it;
+                if (hp < kScNH) in_s[hp * kScInPS + sch] = (ACT && goff[it] >= 0) ? mishf(st[it]) : st[it];
+            }
+        }
+        {   // row f = tid>>3 (+32 i), chunk q = tid&7 at slot q ^ ((f & 15) >> 1); (f + 32 i) & 15 == f & 15
+            const int f = tid >> 3, q = tid & 7;
+            float* wd = w_s + f * kScKC + ((q ^ ((f & 15) >> 1)) << 2);
+            if (F >= 32 || f < F) *reinterpret_cast<float4*>(wd) = wreg0;
+            if (F >= 64) *reinterpret_cast<float4*>(wd + 32 * kScKC) = wreg1;
+            if (F >= 128) {
+                *reinterpret_cast<float4*>(wd + 64 * kScKC) = wreg2;
+                *reinterpret_cast<float4*>(wd + 96 * kScKC) = wreg3;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;   // tap k of channel ch -> dw_s[k][ch]
+            if (idx < kScKC * 9) dw_s[(idx % 9) * kScKC + idx / 9] = dreg[i];
+        }
+    };
+
+    // ---- depthwise map: 4 channels (quad cq) x 4 consecutive pixels of one tile row ----
+    const int cq = tid & 7, strip = tid >> 3;
+    const int drow = strip >> 2, dxs = (strip & 3) * 4;
+    // ---- operand map of the matrix phase ----
+    const int sw = n >> 1;
+
+    fetch(0);
+    for (int c0 = 0; c0 < cpad; c0 += kScKC) {
+        commit(c0);
+        __syncthreads();
+        if (c0 + kScKC < cpad) fetch(c0 + kScKC);
+        {   // depthwise
+            float4 wq[9];   // tap k of this thread's 4 channels
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wq[k] = *reinterpret_cast<const float4*>(dw_s + k * kScKC + 4 * cq);
+            float4 a[4];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) a[px] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float4 r[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    r[j] = *reinterpret_cast<const float4*>(in_s + ((drow + ky) * kScHW + dxs + j) * kScInPS + 4 * cq);
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 v = r[px + kx];
+                        const float4 wk = wq[ky * 3 + kx];
+                        a[px].x = fmaf(wk.x, v.x, a[px].x);
+                        a[px].y = fmaf(wk.y, v.y, a[px].y);
+                        a[px].z = fmaf(wk.z, v.z, a[px].z);
+                        a[px].w = fmaf(wk.w, v.w, a[px].w);
+                    }
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const int pix = drow * kScTW + dxs + px;
+                *reinterpret_cast<float4*>(y_s + pix * kScKC + ((cq ^ ((pix & 15) >> 1)) << 2)) = a[px];
+            }
+        }
+        __syncthreads();
+        // pointwise on the matrix cores: D[f][px] += W[f][k] * y[px][k]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int coff = ((4 * u + g) ^ sw) << 2;
+            f32x4v yv[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                yv[m] = *reinterpret_cast<const f32x4v*>(y_s + (32 * wave + 16 * m + n) * kScKC + coff);
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                const f32x4v wv = *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScKC + coff);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], yv[m][t], acc[m][ft], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // in_s / w_s / y_s are rewritten by the next step
+    }
+    // ---- bias + store: lane = pixel n of a 16-pixel row segment, outputs 16 ft + 4 g .. + 3 ----
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int pix = 32 * wave + 16 * m + n;
+        const int gy = Y0 + pix / kScTW, gx = X0 + pix % kScTW;
+        if (gy < H && gx < W) {
+            float* o = out + ((int64_t)(b * H + gy) * W + gx) * F;
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+                *reinterpret_cast<float4*>(o + 16 * ft + 4 * g) =
+                    make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
+                                acc[m][ft][3] + bv.w);
+            }
         }
     }
 }
 
 template <int F>
-static void sepconv_dispatch(const DwSrc& d, int act, const float* dw, const float* pw, const float* bias,
-                             float* out, int H, int W, int C, int cpad, int tiles_x, int tiles_y,
-                             dim3 grid, hipStream_t s) {
-    if (act)
-        hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, true>), grid, dim3(256), 0, s, d, dw, pw, bias, out,
-                           H, W, C, cpad, tiles_x, tiles_y);
-    else
-        hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, false>), grid, dim3(256), 0, s, d, dw, pw, bias, out,
-                           H, W, C, cpad, tiles_x, tiles_y);
+static void sepconv_dispatch(const DwSrc& d, int act, bool vec, const float* dw, const float* pw,
+                             const float* bias, float* out, int H, int W, int C, int cpad, int tiles_x,
+                             int tiles_y, dim3 grid, hipStream_t s) {
+#define QPWC_SC_LAUNCH(ACT, VEC)                                                                      \
+    hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, ACT, VEC>), grid, dim3(256), 0, s, d, dw, pw, bias, \
+                       out, H, W, C, cpad, tiles_x, tiles_y)
+    if (act) {
+        if (vec) QPWC_SC_LAUNCH(true, true); else QPWC_SC_LAUNCH(true, false);
+    } else {
+        if (vec) QPWC_SC_LAUNCH(false, true); else QPWC_SC_LAUNCH(false, false);
+    }
+#undef QPWC_SC_LAUNCH
 }
 
 int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
@@ -429,14 +542,22 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
         C += d.ch[i];
     }
     const int cpad = (C + kScKC - 1) / kScKC * kScKC;
-    const int tiles_x = (W + kScTile - 1) / kScTile, tiles_y = (H + kScTile - 1) / kScTile;
-    const dim3 grid((unsigned)(tiles_x * tiles_y * B));
+    const int tiles_x = (W + kScTW - 1) / kScTW, tiles_y = (H + kScTH - 1) / kScTH;
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
+    if (nblk > INT32_MAX) {
+        set_error("sepconv3x3: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    const dim3 grid((unsigned)nblk);
+    // one dense source whose pixels are 16-byte aligned runs of a multiple of 4 channels: 16-byte loads
+    const bool vec = n_src == 1 && C % 4 == 0 && strides[0] % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(srcs[0]) % 16 == 0;
     const float *fdw = (const float*)dw, *fpw = (const float*)pw, *fb = (const float*)bias;
     switch (F) {
-        case 128: sepconv_dispatch<128>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 64: sepconv_dispatch<64>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 32: sepconv_dispatch<32>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 16: sepconv_dispatch<16>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 128: sepconv_dispatch<128>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 64: sepconv_dispatch<64>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 32: sepconv_dispatch<32>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 16: sepconv_dispatch<16>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
         default: set_error("sepconv3x3: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
     }
     return check_launch("sepconv3x3_fused_kernel");

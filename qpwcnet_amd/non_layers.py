@@ -242,15 +242,16 @@ class OptFlow(_Weighted):
     times sqrt(h^2 + w^2) of the input's spatial size."""
 
     BN_EPS = 1e-3
-    # Fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd) instead of dwconv + library GEMM:
-    # False / True = never / always, None = per layer by size (_fuse_layer).  Measured inside the
-    # captured step: never 1.87 ms, by-size 1.90 ms, always 2.30 ms -- the kernel reaches 25 TF
-    # against the library GEMM's 75-90 TF, so it stays off; kept (and tested) for later tuning.
-    fused_sepconv = False
+    # Fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd: depthwise result stays in LDS, pointwise
+    # on the fp32 matrix cores) instead of dwconv + library GEMM: False / True = never / always,
+    # None = per layer (_fuse_layer).  tools/sepbench.py, B=8: L4 299 vs 388 us for the four layers,
+    # L3 97 vs 138; wide layers of a small level (few 8x16 tiles, many 32-channel steps) are faster
+    # split (first layer at L2 37 vs 23 us, at L0 82 vs 12 us; 128-channel layer at L0/L1 15 vs 10 us).
+    fused_sepconv = None
 
     @staticmethod
-    def _fuse_layer(c_in, n_pixels):
-        return c_in <= 64 or (c_in <= 128 and n_pixels <= 16384)
+    def _fuse_layer(c_in, n_tiles):
+        return c_in <= 64 or (c_in <= 128 and n_tiles >= 128) or n_tiles >= 256
 
     def __init__(self, params, prefix, filters=(128, 64, 32, 16), scale=None, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
@@ -293,7 +294,8 @@ class OptFlow(_Weighted):
         for i in range(len(self.filters)):
             src = sources if i == 0 else [z]
             c_in = self._dw[i].shape[0]
-            fused = fp32 and (self._fuse_layer(c_in, B * H * W) if self.fused_sepconv is None
+            n_tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
+            fused = fp32 and (self._fuse_layer(c_in, n_tiles) if self.fused_sepconv is None
                               else bool(self.fused_sepconv))
             if fused:  # depthwise + pointwise + bias in one launch, depthwise result stays on chip
                 z = ops.sepconv3x3(src, self._dw[i], self._pw_pad[i], self._pw_b32[i], mish_on_load=i > 0)

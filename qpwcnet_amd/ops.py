@@ -428,11 +428,11 @@ def _dw_sources(sources):
 
 
 def pad_pointwise(pw):
-    """(F, C[,1,1]) pointwise kernel -> dense fp32 (F, ceil(C/16)*16), zero padded: the
+    """(F, C[,1,1]) pointwise kernel -> dense fp32 (F, ceil(C/32)*32), zero padded: the
     layout qpwc_sepconv3x3_fwd takes."""
     pw = pw.reshape(pw.shape[0], -1).float()
     F_, C = pw.shape
-    cpad = (C + 15) // 16 * 16
+    cpad = (C + 31) // 32 * 32
     out = torch.zeros((F_, cpad), dtype=torch.float32, device=pw.device)
     out[:, :C] = pw
     return out
@@ -448,7 +448,7 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False):
         raise ValueError("sepconv3x3 is fp32 only")
     F_ = pw_padded.shape[0]
     w = dw.reshape(-1, 9)
-    if w.shape[0] != C or pw_padded.shape[1] != (C + 15) // 16 * 16 or bias.numel() != F_:
+    if w.shape[0] != C or pw_padded.shape[1] != (C + 31) // 32 * 32 or bias.numel() != F_:
         raise ValueError("weight shapes do not match C = {}".format(C))
     for t in (w, pw_padded, bias):
         if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():

@@ -186,15 +186,19 @@ def test_optflow_fused_and_unfused_sepconv_agree():
     srcs = [t.to(DEV) for t in (_rand(rng, 2, *hw, 81), _rand(rng, 2, *hw, 128), _rand(rng, 2, *hw, 2))]
     params = {k: torch.as_tensor(v).to(DEV) for k, v in weights.items()}
     of = non_layers.OptFlow(params, "upflow.1.flow.", data_format="channels_last")
+    default = non_layers.OptFlow.fused_sepconv
     try:
         non_layers.OptFlow.fused_sepconv = True
         a = of.from_sources(srcs).cpu()
         non_layers.OptFlow.fused_sepconv = False
         b = of.from_sources(srcs).cpu()
+        non_layers.OptFlow.fused_sepconv = None      # per layer by size (the default)
+        c = of.from_sources(srcs).cpu()
     finally:
-        non_layers.OptFlow.fused_sepconv = False
+        non_layers.OptFlow.fused_sepconv = default
     scale = float(hw[0] ** 2 + hw[1] ** 2) ** 0.5
     torch.testing.assert_close(a / scale, b / scale, rtol=0, atol=2e-5)
+    torch.testing.assert_close(c / scale, b / scale, rtol=0, atol=2e-5)
 
 
 def test_bias_mish_pad():
