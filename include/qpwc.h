@@ -141,11 +141,13 @@ int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
 
 /* The whole SeparableConv2D(3x3,'same') before its activation, fp32, in one launch:
  *   out[b,y,x,f] = bias[f] + sum_c pw[f,c] * (depthwise3x3(in0))[b,y,x,c]
- * with `in`/`in0` as in qpwc_dwconv3x3_fwd (1..3 sources, optional Mish on load); the
+ * with `in`/`in0` as in qpwc_dwconv3x3_fwd (1..3 sources); mish_flags: bit 0 = Mish on load (the
+ * input is a pre-activation tensor), bit 1 = store Mish(out) (the SeparableConv2D's own
+ * `activation='Mish'`, non_layers.py:226, applied once per element instead of at the next load); the
  * depthwise result stays on chip (LDS -> matrix cores).  dw: (C,3,3); pw: (F, Cpad) row-major,
  * Cpad = ceil(C/32)*32, zero padded; bias: (F); F in {16,32,64,128}; out: (B,H,W,F) dense. */
 int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
-                        const int64_t* src_pixel_stride, int n_src, int mish_on_load,
+                        const int64_t* src_pixel_stride, int n_src, int mish_flags,
                         const void* dw, const void* pw, const void* bias, void* out,
                         int B, int H, int W, int F, void* stream);
 

@@ -230,7 +230,7 @@ int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
 }
 
 int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
-                        const int64_t* src_pixel_stride, int n_src, int mish_on_load, const void* dw,
+                        const int64_t* src_pixel_stride, int n_src, int mish_flags, const void* dw,
                         const void* pw, const void* bias, void* out, int B, int H, int W, int F,
                         void* stream) {
     if (!src || !src_channels || !src_pixel_stride || !dw || !pw || !bias || !out)
@@ -249,7 +249,8 @@ int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
     }
     if ((uintptr_t)out % 16 || (uintptr_t)pw % 16 || (uintptr_t)bias % 16 || (uintptr_t)dw % 4)
         return fail(QPWC_E_ALIGN, "out, pw, bias must be 16-byte aligned");
-    return sepconv3x3_launch(src, src_channels, src_pixel_stride, n_src, mish_on_load, dw, pw, bias, out, B,
+    if (mish_flags < 0 || mish_flags > 3) return fail(QPWC_E_SHAPE, "mish_flags %d outside [0,3]", mish_flags);
+    return sepconv3x3_launch(src, src_channels, src_pixel_stride, n_src, mish_flags, dw, pw, bias, out, B,
                              H, W, F, (hipStream_t)stream);
 }
 

@@ -314,7 +314,7 @@ constexpr int kScHH = kScTH + 2, kScHW = kScTW + 2;
 constexpr int kScNH = kScHH * kScHW;    // 180 halo pixels
 constexpr int kScInPS = 40;             // floats per halo pixel in in_s
 
-template <int F, bool ACT, bool VEC>
+template <int F, bool ACT, bool VEC, bool ACT_OUT>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     DwSrc src, const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y) {
@@ -507,9 +507,12 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 #pragma unroll
             for (int ft = 0; ft < NFT; ++ft) {
                 const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
-                *reinterpret_cast<float4*>(o + 16 * ft + 4 * g) =
-                    make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
-                                acc[m][ft][3] + bv.w);
+                float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
+                                       acc[m][ft][3] + bv.w);
+                // the activation applied once per output element instead of once per (halo) load
+                // of the next layer
+                if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
+                *reinterpret_cast<float4*>(o + 16 * ft + 4 * g) = z;
             }
         }
     }
@@ -519,13 +522,16 @@ template <int F>
 static void sepconv_dispatch(const DwSrc& d, int act, bool vec, const float* dw, const float* pw,
                              const float* bias, float* out, int H, int W, int C, int cpad, int tiles_x,
                              int tiles_y, dim3 grid, hipStream_t s) {
-#define QPWC_SC_LAUNCH(ACT, VEC)                                                                      \
-    hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, ACT, VEC>), grid, dim3(256), 0, s, d, dw, pw, bias, \
+#define QPWC_SC_LAUNCH(ACT, VEC, AO)                                                                      \
+    hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, ACT, VEC, AO>), grid, dim3(256), 0, s, d, dw, pw, bias, \
                        out, H, W, C, cpad, tiles_x, tiles_y)
-    if (act) {
-        if (vec) QPWC_SC_LAUNCH(true, true); else QPWC_SC_LAUNCH(true, false);
+    const bool in_act = (act & 1) != 0, out_act = (act & 2) != 0;   // QPWC_MISH_ON_LOAD / _ON_STORE
+    if (out_act) {
+        if (in_act) { if (vec) QPWC_SC_LAUNCH(true, true, true); else QPWC_SC_LAUNCH(true, false, true); }
+        else        { if (vec) QPWC_SC_LAUNCH(false, true, true); else QPWC_SC_LAUNCH(false, false, true); }
     } else {
-        if (vec) QPWC_SC_LAUNCH(false, true); else QPWC_SC_LAUNCH(false, false);
+        if (in_act) { if (vec) QPWC_SC_LAUNCH(true, true, false); else QPWC_SC_LAUNCH(true, false, false); }
+        else        { if (vec) QPWC_SC_LAUNCH(false, true, false); else QPWC_SC_LAUNCH(false, false, false); }
     }
 #undef QPWC_SC_LAUNCH
 }

@@ -290,18 +290,32 @@ class OptFlow(_Weighted):
         B, H, W = sources[0].shape[:3]
         scale = self.scale if self.scale is not None else float(H ** 2 + W ** 2) ** 0.5
         z = None
+        z_act = False   # z already carries its layer's Mish (fused layers store it activated)
         fp32 = sources[0].dtype == torch.float32
-        for i in range(len(self.filters)):
+        n_layers = len(self.filters)
+        n_tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
+
+        def fuse(i):
+            if not fp32 or i >= n_layers:
+                return False
+            if self.fused_sepconv is None:
+                return self._fuse_layer(self._dw[i].shape[0], n_tiles)
+            return bool(self.fused_sepconv)
+
+        for i in range(n_layers):
             src = sources if i == 0 else [z]
-            c_in = self._dw[i].shape[0]
-            n_tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
-            fused = fp32 and (self._fuse_layer(c_in, n_tiles) if self.fused_sepconv is None
-                              else bool(self.fused_sepconv))
-            if fused:  # depthwise + pointwise + bias in one launch, depthwise result stays on chip
-                z = ops.sepconv3x3(src, self._dw[i], self._pw_pad[i], self._pw_b32[i], mish_on_load=i > 0)
+            act_in = i > 0 and not z_act
+            if fuse(i):  # depthwise + pointwise + bias in one launch, depthwise result stays on chip
+                # store Mish(z) when the next consumer is another fused layer (the flow head and the
+                # split depthwise kernel take pre-activation tensors and activate on load)
+                act_out = fuse(i + 1)
+                z = ops.sepconv3x3(src, self._dw[i], self._pw_pad[i], self._pw_b32[i], mish_on_load=act_in,
+                                   mish_on_store=act_out)
+                z_act = act_out
             else:
-                y = ops.dwconv3x3(src, self._dw[i], mish_on_load=i > 0)
+                y = ops.dwconv3x3(src, self._dw[i], mish_on_load=act_in)
                 z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1), self._pw_t[i]).view(B, H, W, -1)
+                z_act = False
         return ops.flow_head(z, self._head, scale)
 
     def __call__(self, inputs):

@@ -438,11 +438,12 @@ def pad_pointwise(pw):
     return out
 
 
-def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False):
-    """SeparableConv2D(3x3,'same') without its activation, fused (fp32): depthwise 3x3 over
-    the virtual concat of 1..3 channels-last sources, pointwise 1x1 + bias on the matrix
-    cores (qpwcnet/core/non_layers.py:223-231).  pw_padded from pad_pointwise().
-    -> pre-activation (B,H,W,F)."""
+def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False, mish_on_store=False):
+    """SeparableConv2D(3x3,'same'), fused (fp32): depthwise 3x3 over the virtual concat of 1..3
+    channels-last sources, pointwise 1x1 + bias on the matrix cores
+    (qpwcnet/core/non_layers.py:223-231).  pw_padded from pad_pointwise().
+    -> (B,H,W,F): the pre-activation output, or Mish of it with mish_on_store (the layer's own
+    `activation='Mish'` applied once per element; the consumer then loads without Mish)."""
     keep, c_ptrs, c_ch, c_st, B, H, W, C = _dw_sources(sources)
     if keep[0].dtype != torch.float32:
         raise ValueError("sepconv3x3 is fp32 only")
@@ -455,7 +456,8 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False):
             raise ValueError("weights must be dense fp32 device tensors")
     out = torch.empty((B, H, W, F_), dtype=torch.float32, device=keep[0].device)
     with torch.cuda.device(out.device), _timed("sepconv3x3", (B, H, W, C, F_)):
-        rc = _hip.lib().qpwc_sepconv3x3_fwd(c_ptrs, c_ch, c_st, len(keep), int(bool(mish_on_load)),
+        rc = _hip.lib().qpwc_sepconv3x3_fwd(c_ptrs, c_ch, c_st, len(keep),
+                                             int(bool(mish_on_load)) | (2 if mish_on_store else 0),
                                              w.data_ptr(), pw_padded.data_ptr(), bias.data_ptr(),
                                              out.data_ptr(), B, H, W, F_, _stream(out))
     _hip.check(rc)

@@ -177,6 +177,10 @@ def test_sepconv3x3_fused(chans, F, hw, act):
                          bias.to(DEV), mish_on_load=act).cpu()
     assert out.shape == ref.shape
     torch.testing.assert_close(out, ref, rtol=0, atol=5e-5)
+    # the layer's own activation applied at the store (what a following fused layer consumes)
+    out_act = ops.sepconv3x3([s.to(DEV) for s in srcs], dw.to(DEV), ops.pad_pointwise(pw.to(DEV)),
+                             bias.to(DEV), mish_on_load=act, mish_on_store=True).cpu()
+    torch.testing.assert_close(out_act, torch_ref.mish(ref), rtol=0, atol=5e-5)
 
 
 def test_optflow_fused_and_unfused_sepconv_agree():
