@@ -43,6 +43,8 @@ def parse_args():
     p.add_argument("--fused", dest="fused", action="store_true", default=False,
                    help="fused warp+cost-volume UpFlow front end")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-inflight", action="store_true",
+                   help="skip the extra '2 batches in flight' throughput measurement (N=1 only)")
     p.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                    help="f16 = BASELINE configs[4] (fp16 storage / convs, fp32 accumulate in the hot path)")
     p.add_argument("--dist-backend", default=None,
@@ -143,6 +145,34 @@ def main():
     torch.cuda.synchronize()
     elapsed = qdist.max_over_ranks(time.perf_counter() - t0, dev)
 
+    # ---- serving-style throughput, reported BESIDE the headline (never as `value`): two batches of 8
+    # in flight, each a hipGraph replay on its own stream, so that the launch-bound coarse levels of
+    # one batch run under the encoder / finest level of the other.  Same K steps, same work per step.
+    serving = None
+    if graph is not None and world == 1 and not args.no_inflight:
+        pairs2_np, _ = synth.make_frames(B, hw[0], hw[1], seed=4321)
+        g2 = GraphedForward(model, torch.from_numpy(pairs2_np).to(dev, tdtype),
+                            epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=0)
+        lanes = [(torch.cuda.Stream(), graph), (torch.cuda.Stream(), g2)]
+        torch.cuda.synchronize()
+
+        def run(n):
+            for i in range(n):
+                st, g = lanes[i & 1]
+                with torch.cuda.stream(st):
+                    g.replay()
+
+        run(max(2, args.warmup))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        serving = {"batches_in_flight": 2, "value": B * args.steps / dt, "unit": "pairs/s",
+                   "ms_per_step": dt / args.steps * 1e3,
+                   "note": "two hipGraph replays (batch 8 each) on two streams; not the headline value"}
+        del g2
+
     # ---- live roofline of the dominant hot-path kernel: HIP events on the launch stream
     # (single stream for this pass: with the decoder running beside it on the side stream the
     # events would time the kernel while it shares the chip)
@@ -237,6 +267,7 @@ def main():
                            for k, (n, t) in sorted(ktimes.items())},
         },
         "per_level_epe_vs_ground_truth": [float(x) for x in epe_mean.cpu()],
+        "serving_throughput": serving,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
