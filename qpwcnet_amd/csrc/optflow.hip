@@ -576,19 +576,29 @@ constexpr int kFhC = 16;
 constexpr int kFhTile = 16;
 constexpr int kFhParams = 592;  // == qpwc_flow_head_param_floats()
 
+// Both convolutions run lane = (pixel n, channel quad g), n = lane & 15, g = lane >> 4:
+//   1x1 conv : v_mfma_f32_16x16x4_f32, rows = the 16 outputs (A = W1: 4 registers, loaded once), cols =
+//              16 pixels; a lane's B operand is Mish of its own 16-byte load of z, and the result lane
+//              holds outputs 4g..4g+3 of pixel n -> + b1, Mish, BatchNorm -> one ds_write_b128 of h;
+//   3x3 conv : each lane keeps the 72 weights of its 4 input channels, accumulates its partial
+//              (fx, fy) over the 9 taps from ds_read_b128 of h, and the four quads of a pixel are
+//              added with two wave shuffles.
+// No weight streams through scalar registers any more (the 592 parameters, re-fetched by s_load
+// for every pixel round, made the old form latency bound: 15 us at every level).
 template <typename T>
-__global__ __launch_bounds__(256, 4) void flow_head_kernel(const T* __restrict__ z,
+__global__ __launch_bounds__(256, 2) void flow_head_kernel(const T* __restrict__ z,
                                                            const float* __restrict__ params,
                                                            T* __restrict__ out, int H, int W,
                                                            int tiles_x, int tiles_y, float scale) {
     constexpr int TW = kFhTile + 2;
-    __shared__ __attribute__((aligned(16))) float hs[TW * TW * kFhC];  // 18*18*16*4 = 20.7 KB
+    constexpr int NH = TW * TW;                                        // 324 halo pixels
+    __shared__ __attribute__((aligned(16))) float hs[(NH + 12) * kFhC];  // 21 groups of 16 pixels
     const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int x0 = tx * kFhTile, y0 = ty * kFhTile;
-    // parameters are read with compile-time offsets from the (uniform) kernel argument:
-    // scalar loads, the weights sit in SGPRs as FMA operands
     const float* w1 = params;
     const float* b1 = params + 256;
     const float* bs = params + 272;
@@ -596,59 +606,64 @@ __global__ __launch_bounds__(256, 4) void flow_head_kernel(const T* __restrict__
     const float* wf = params + 304;
     const T* zb = z + (int64_t)b * H * W * kFhC;
 
-    // stage h3 = BN(mish(W1 mish(z) + b1)) for the tile + 1 halo; zero outside the image
-    for (int p = tid; p < TW * TW; p += 256) {
-        const int ly = p / TW, lx = p - ly * TW;
+    // ---- h = BN(mish(W1 mish(z) + b1)) for the tile + 1 halo; zero outside the image ----
+    const f32x4v w1v = *reinterpret_cast<const f32x4v*>(w1 + n * kFhC + 4 * g);   // W1[f = n][4g..4g+3]
+    const float4 b1v = *reinterpret_cast<const float4*>(b1 + 4 * g);
+    const float4 bsv = *reinterpret_cast<const float4*>(bs + 4 * g);
+    const float4 btv = *reinterpret_cast<const float4*>(bt + 4 * g);
+    for (int grp = wave; grp < (NH + 15) / 16; grp += 4) {
+        const int hp = 16 * grp + n;
+        const int ly = hp / TW, lx = hp - ly * TW;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-        float h[kFhC];
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const T* q = zb + ((int64_t)gy * W + gx) * kFhC;
-            float a[kFhC];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = ld4(q + 4 * i);
-                a[4 * i] = mishf(v.x); a[4 * i + 1] = mishf(v.y);
-                a[4 * i + 2] = mishf(v.z); a[4 * i + 3] = mishf(v.w);
-            }
-#pragma unroll
-            for (int o = 0; o < kFhC; ++o) {
-                float s = b1[o];
-#pragma unroll
-                for (int i = 0; i < kFhC; ++i) s = fmaf(w1[o * kFhC + i], a[i], s);
-                h[o] = fmaf(mishf(s), bs[o], bt[o]);
-            }
-        } else {
-#pragma unroll
-            for (int o = 0; o < kFhC; ++o) h[o] = 0.0f;
+        const bool in = hp < NH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            a = ld4(zb + ((int64_t)gy * W + gx) * kFhC + 4 * g);
+            a = make_float4(mishf(a.x), mishf(a.y), mishf(a.z), mishf(a.w));
         }
-        float4* d = reinterpret_cast<float4*>(hs + p * kFhC);
+        f32x4v d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[0], a.x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[1], a.y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[2], a.z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[3], a.w, d, 0, 0, 0);
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in)
+            h = make_float4(fmaf(mishf(d[0] + b1v.x), bsv.x, btv.x), fmaf(mishf(d[1] + b1v.y), bsv.y, btv.y),
+                            fmaf(mishf(d[2] + b1v.z), bsv.z, btv.z), fmaf(mishf(d[3] + b1v.w), bsv.w, btv.w));
+        *reinterpret_cast<float4*>(hs + hp * kFhC + 4 * g) = h;
+    }
+    // the 72 weights of this lane's 4 input channels: wf[ky][kx][in][out]
+    float4 wq[9][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = make_float4(h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+    for (int k = 0; k < 9; ++k) {
+        wq[k][0] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g);       // (c0:x,y) (c1:x,y)
+        wq[k][1] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g + 4);   // (c2:x,y) (c3:x,y)
     }
     __syncthreads();
 
-    const int lx = tid % kFhTile, ly = tid / kFhTile;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= W || gy >= H) return;
-    float fx = 0.0f, fy = 0.0f;
+    // ---- 3x3 conv 16 -> 2: a wave takes tile rows wave, wave+4, ...; lane = (column n, quad g) ----
+    for (int ry = wave; ry < kFhTile; ry += 4) {
+        float fx = 0.0f, fy = 0.0f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const float4* q = reinterpret_cast<const float4*>(hs + ((ly + ky) * TW + lx + kx) * kFhC);
-            const float* wk = wf + (ky * 3 + kx) * kFhC * 2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = q[i];
-                fx = fmaf(v.x, wk[(4 * i) * 2], fx);     fy = fmaf(v.x, wk[(4 * i) * 2 + 1], fy);
-                fx = fmaf(v.y, wk[(4 * i + 1) * 2], fx); fy = fmaf(v.y, wk[(4 * i + 1) * 2 + 1], fy);
-                fx = fmaf(v.z, wk[(4 * i + 2) * 2], fx); fy = fmaf(v.z, wk[(4 * i + 2) * 2 + 1], fy);
-                fx = fmaf(v.w, wk[(4 * i + 3) * 2], fx); fy = fmaf(v.w, wk[(4 * i + 3) * 2 + 1], fy);
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 v = *reinterpret_cast<const float4*>(hs + ((ry + ky) * TW + n + kx) * kFhC + 4 * g);
+                const float4 wa = wq[ky * 3 + kx][0], wb = wq[ky * 3 + kx][1];
+                fx = fmaf(v.x, wa.x, fx); fy = fmaf(v.x, wa.y, fy);
+                fx = fmaf(v.y, wa.z, fx); fy = fmaf(v.y, wa.w, fy);
+                fx = fmaf(v.z, wb.x, fx); fy = fmaf(v.z, wb.y, fy);
+                fx = fmaf(v.w, wb.z, fx); fy = fmaf(v.w, wb.w, fy);
             }
+        fx += __shfl_xor(fx, 16); fy += __shfl_xor(fy, 16);
+        fx += __shfl_xor(fx, 32); fy += __shfl_xor(fy, 32);
+        const int gx = x0 + n, gy = y0 + ry;
+        if (g == 0 && gx < W && gy < H) {
+            T* o = out + ((int64_t)(b * H + gy) * W + gx) * 2;
+            st(o, scale * fx);
+            st(o + 1, scale * fy);
         }
-    T* o = out + ((int64_t)(b * H + gy) * W + gx) * 2;
-    st(o, scale * fx);
-    st(o + 1, scale * fy);
+    }
 }
 
 // ---------------------------------------------------------------------------

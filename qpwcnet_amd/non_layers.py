@@ -463,14 +463,21 @@ class FrameInterpolate(_Weighted):
                 src = [torch.cat([prv_w, nxt_w, small], dim=3)]
             else:
                 src = [prv_w, nxt_w, small]
-            y = ops.dwconv3x3(src, self.p32("conv1.depthwise.weight").reshape(-1, 9))
             key = self.prefix + "#gemm"
             mats = self.params.get(key)
             if mats is None:
                 mats = self.params[key] = (pw.reshape(pw.shape[0], -1).t().contiguous(),
-                                           w2.reshape(w2.shape[0], -1).t().contiguous())
-            z = torch.mm(y.view(B * H * W, -1), mats[0]).view(B, H, W, -1)
-            ops.bias_mish_(z, self.p32("conv1.bias"))
+                                           w2.reshape(w2.shape[0], -1).t().contiguous(),
+                                           ops.pad_pointwise(pw))
+            dw9 = self.p32("conv1.depthwise.weight").reshape(-1, 9)
+            n_tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
+            if prv_w.dtype == torch.float32 and OptFlow._fuse_layer(dw9.shape[0], n_tiles):
+                # SeparableConv2D + Mish in one launch (depthwise result stays on chip)
+                z = ops.sepconv3x3(src, dw9, mats[2], self.p32("conv1.bias"), mish_on_store=True)
+            else:
+                y = ops.dwconv3x3(src, dw9)
+                z = torch.mm(y.view(B * H * W, -1), mats[0]).view(B, H, W, -1)
+                ops.bias_mish_(z, self.p32("conv1.bias"))
             return torch.addmm(self.p("conv2.bias"), z.view(B * H * W, -1), mats[1]).view(B, H, W, -1)
         x = self._nchw(torch.cat([prv_w, nxt_w] + list(rest), dim=self.axis))
         x = F.conv2d(x, dw, None, stride=1, padding=1, groups=dw.shape[0])
