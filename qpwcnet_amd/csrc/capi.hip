@@ -57,6 +57,8 @@ int invert_flow_launch(const void* flow, void* out, int B, int H, int W, int lay
                        hipStream_t s);
 int occlusion_launch(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
                      hipStream_t s);
+int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                        int C, int pad_h, int pad_w, hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
@@ -367,6 +369,19 @@ int qpwc_occlusion_fwd(const void* flow, void* out, int B, int H, int W, int lay
     if (rc) return rc;
     if ((uintptr_t)out % 4) return fail(QPWC_E_ALIGN, "out must be 4-byte aligned");
     return occlusion_launch(flow, out, B, H, W, layout, dtype, (hipStream_t)stream);
+}
+
+int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,
+                          int W, int C, int pad_h, int pad_w, void* stream) {
+    if (!x || !weight || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (C != 16 && C != 32) return fail(QPWC_E_SHAPE, "C=%d not in {16,32}", C);
+    if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || pad_h > 8 || pad_w > 8)
+        return fail(QPWC_E_SHAPE, "bad shape B=%d H=%d W=%d pad=%d,%d", B, H, W, pad_h, pad_w);
+    if ((uintptr_t)x % 16 || (uintptr_t)weight % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
+        return fail(QPWC_E_ALIGN, "x, weight, bias, out must be 16-byte aligned");
+    if (overlaps(out, (size_t)B * (H + pad_h) * (W + pad_w) * C * 4, x, (size_t)B * H * W * C * 4))
+        return fail(QPWC_E_ALIAS, "out overlaps x");
+    return conv3x3_mish_launch(x, weight, bias, out, B, H, W, C, pad_h, pad_w, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,144 @@
+// 3x3 stride-1 'same' convolution + bias + Mish of the encoder's DownConv blocks
+// (conv_aa / conv_b, qpwcnet/core/non_layers.py:410-449 with use_normalizer=False, pwcnet.py:146)
+// for the narrow levels (C_in = C_out = 16 or 32), channels-last fp32, gfx950.
+//
+// At 16 / 32 channels the layer is a K = 144 / 288, N = 16 / 32 implicit GEMM over 0.5 M / 0.13 M
+// pixels: 2.4 GFLOP against 67 / 34 MB of activations.  The library kernels run it at 45-58 TF and
+// need a separate bias+Mish pass; here the tile's halo lives in LDS, the nine shifted views of it are
+// the B operands of v_mfma_f32_16x16x4_f32 (rows = output channels, cols = 16 pixels of a tile row),
+// the weights of a wave's output block sit in registers for the whole tile, and bias + Mish (and the
+// zero border the next stride-2 convolution's 'SAME' padding needs) are the epilogue.
+//
+// Workgroup = 4 waves = an 8 x 16 pixel tile; a wave owns two tile rows.  k-slot g of a lane owns
+// channels 4g..4g+3 of a 16-channel chunk, so every operand is one 16-byte access; LDS pixels are
+// C floats with the 16-byte chunk c of halo pixel p stored at chunk c ^ ((p >> 1) & (C/4 - 1)) for
+// C = 32 (C = 16: a wave reads 1 KB contiguous, no swizzle needed).
+#include "common.h"
+
+namespace qpwc {
+
+// (same fast form as optflow.hip's mishf)
+__device__ __forceinline__ float enc_mishf(float x) {
+    const float e = __expf(fminf(x, 20.0f));
+    const float t = e * (e + 2.0f);
+    const float m = x * __fdividef(t, t + 2.0f);
+    return x > 20.0f ? x : m;
+}
+
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+
+constexpr int kEcTH = 8, kEcTW = 16;
+constexpr int kEcHW = kEcTW + 2, kEcNH = (kEcTH + 2) * kEcHW;   // 180 halo pixels
+
+// weight: [9 taps][C out][C in] fp32; out: (B, H + pad_h, W + pad_w, C), border zero
+template <int C>
+__global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ weight,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ out, int H, int W,
+                                                              int pad_h, int pad_w, int tiles_x, int tiles_y) {
+    constexpr int NQ = C / 4;     // 16-byte chunks per pixel
+    constexpr int NFT = C / 16;   // output blocks of 16 channels
+    constexpr int NKC = C / 16;   // 16-channel k chunks
+    __shared__ __attribute__((aligned(16))) float in_s[kEcNH * C];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * kEcTH;
+    const float* xb = x + (int64_t)b * H * W * C;
+
+    // ---- stage the halo tile (zero outside the image) ----
+    for (int idx = tid; idx < kEcNH * NQ; idx += 256) {
+        const int hp = idx / NQ, q = idx - hp * NQ;
+        const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
+        const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)gy * W + gx) * C + 4 * q);
+        const int slot = C == 16 ? q : (q ^ ((hp >> 1) & (NQ - 1)));
+        *reinterpret_cast<float4*>(in_s + hp * C + 4 * slot) = v;
+    }
+    __syncthreads();
+
+    const int Ho = H + pad_h, Wo = W + pad_w;
+    float* ob = out + (int64_t)b * Ho * Wo * C;
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        // weights of output block ft for this lane: row f = 16 ft + n, channels 16 kc + 4g .. + 3, 9 taps
+        f32x4e wv[9][NKC];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc)
+                wv[k][kc] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)k * C + 16 * ft + n) * C + 16 * kc + 4 * g);
+        f32x4e acc[2];
+        acc[0] = f32x4e{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4e{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int hp = (2 * wave + m + ky) * kEcHW + n + kx;
+                        const int q = 4 * kc + g;
+                        const int slot = C == 16 ? q : (q ^ ((hp >> 1) & (NQ - 1)));
+                        const f32x4e bv = *reinterpret_cast<const f32x4e*>(in_s + hp * C + 4 * slot);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[t], acc[m], 0, 0, 0);
+                    }
+        // ---- bias + Mish: lane = pixel n of tile row 2 wave + m, outputs 16 ft + 4g .. + 3 ----
+        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int gy = Y0 + 2 * wave + m, gx = X0 + n;
+            if (gy < H && gx < W)
+                *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * C + 16 * ft + 4 * g) =
+                    make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
+                                enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
+        }
+    }
+    // ---- zero border of the padded output (columns W.., rows H..), written by the edge tiles ----
+    if (pad_w > 0 && X0 + kEcTW >= W) {
+        for (int i = tid; i < kEcTH * pad_w * NQ; i += 256) {
+            const int q = i % NQ, r = i / NQ, col = r % pad_w, row = r / pad_w;
+            const int gy = Y0 + row;
+            if (gy < H) *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + W + col) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (pad_h > 0 && Y0 + kEcTH >= H) {
+        const int x_end = (X0 + kEcTW >= W) ? Wo : X0 + kEcTW;   // the corner belongs to the last tile
+        for (int i = tid; i < pad_h * (x_end - X0) * NQ; i += 256) {
+            const int q = i % NQ, r = i / NQ, col = r % (x_end - X0), row = r / (x_end - X0);
+            *reinterpret_cast<float4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                        int C, int pad_h, int pad_w, hipStream_t s) {
+    const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + kEcTH - 1) / kEcTH;
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
+    if (nblk > INT32_MAX) {
+        set_error("conv3x3_mish: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    const dim3 grid((unsigned)nblk);
+    if (C == 16)
+        hipLaunchKernelGGL(conv3x3_mish_kernel<16>, grid, dim3(256), 0, s, (const float*)x, (const float*)weight,
+                           (const float*)bias, (float*)out, H, W, pad_h, pad_w, tiles_x, tiles_y);
+    else if (C == 32)
+        hipLaunchKernelGGL(conv3x3_mish_kernel<32>, grid, dim3(256), 0, s, (const float*)x, (const float*)weight,
+                           (const float*)bias, (float*)out, H, W, pad_h, pad_w, tiles_x, tiles_y);
+    else {
+        set_error("conv3x3_mish: C=%d not in {16,32}", C);
+        return QPWC_E_SHAPE;
+    }
+    return check_launch("conv3x3_mish_kernel");
+}
+
+}  // namespace qpwc

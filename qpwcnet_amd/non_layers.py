@@ -224,16 +224,40 @@ class DownConv(_Weighted):
         else:
             y = conv2d_same(self._nchw(x), self.p("conv_a.weight"), None, 2)
         y = _bias_mish(y, self.p("conv_a.bias"), self.p32("conv_a.bias"), self.data_format)
+        h, w = y.shape[2], y.shape[3]
+        pad_ok = want_padded and _same_pad(h, 3, 2) == (0, 1) and _same_pad(w, 3, 2) == (0, 1)
+        if self._hip_conv_ok(y):
+            # narrow levels: conv + bias + Mish (+ the next level's 'SAME' padding) in one HIP launch each
+            taps = self._taps()
+            y1 = ops.conv3x3_mish(y.permute(0, 2, 3, 1), taps[0], self.p32("conv_aa.bias"))
+            pad = 1 if pad_ok else 0
+            y2 = ops.conv3x3_mish(y1, taps[1], self.p32("conv_b.bias"), pad, pad)
+            if pad_ok:
+                return y2[:, :h, :w, :], y2
+            return y2, None
         y = conv2d_same(y, self.p("conv_aa.weight"), None, 1)
         y = _bias_mish(y, self.p("conv_aa.bias"), self.p32("conv_aa.bias"), self.data_format)
         y = conv2d_same(y, self.p("conv_b.weight"), None, 1)
-        h, w = y.shape[2], y.shape[3]
-        if (want_padded and _hip_act_ok(y, self.data_format) and _same_pad(h, 3, 2) == (0, 1) and
-                _same_pad(w, 3, 2) == (0, 1)):
+        if pad_ok and _hip_act_ok(y, self.data_format):
             padded = ops.bias_mish_pad(y.permute(0, 2, 3, 1), self.p32("conv_b.bias"), 1, 1)
             return padded[:, :h, :w, :], padded
         y = _bias_mish(y, self.p("conv_b.bias"), self.p32("conv_b.bias"), self.data_format)
         return self._fmt(y), None
+
+    # own 3x3 kernel for the levels where the library runs far below the matrix peak (16 / 32 channels)
+    hip_conv = True
+
+    def _hip_conv_ok(self, y_nchw):
+        return (self.hip_conv and y_nchw.dtype == torch.float32 and y_nchw.shape[1] in (16, 32) and
+                _hip_act_ok(y_nchw, self.data_format))
+
+    def _taps(self):
+        key = self.prefix + "#taps"
+        t = self.params.get(key)
+        if t is None:
+            t = self.params[key] = (ops.conv3x3_taps(self.p("conv_aa.weight")),
+                                    ops.conv3x3_taps(self.p("conv_b.weight")))
+        return t
 
 
 class OptFlow(_Weighted):

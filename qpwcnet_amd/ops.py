@@ -464,6 +464,32 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False, mish_on_store=F
     return out
 
 
+def conv3x3_taps(weight):
+    """torch Conv2d weight (C_out, C_in, 3, 3) -> the (9, C_out, C_in) fp32 tap-major layout of
+    qpwc_conv3x3_mish_fwd."""
+    return weight.float().permute(2, 3, 0, 1).reshape(9, weight.shape[0], weight.shape[1]).contiguous()
+
+
+def conv3x3_mish(x_nhwc, taps, bias, pad_h=0, pad_w=0):
+    """Mish(conv3x3_same(x) + bias) for C_in = C_out in {16, 32}, channels-last fp32 (the encoder's
+    conv_aa / conv_b, non_layers.py:410-449), written into a (B, H+pad_h, W+pad_w, C) tensor whose
+    border is zero (the 'SAME' padding of a following stride-2 conv).  taps from conv3x3_taps()."""
+    _check_tensor("x", x_nhwc)
+    if x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous():
+        raise ValueError("conv3x3_mish needs a dense fp32 channels-last tensor")
+    B, H, W, C = x_nhwc.shape
+    if tuple(taps.shape) != (9, C, C) or taps.dtype != torch.float32 or not taps.is_cuda or \
+            not taps.is_contiguous() or bias.numel() != C or bias.dtype != torch.float32 or not bias.is_cuda:
+        raise ValueError("taps must be a dense fp32 (9,{0},{0}) device tensor, bias fp32 ({0})".format(C))
+    out = torch.empty((B, H + pad_h, W + pad_w, C), dtype=torch.float32, device=x_nhwc.device)
+    with torch.cuda.device(out.device), _timed("conv3x3_mish", (B, H, W, C)):
+        rc = _hip.lib().qpwc_conv3x3_mish_fwd(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(),
+                                              out.data_ptr(), B, H, W, C, int(pad_h), int(pad_w),
+                                              _stream(out))
+    _hip.check(rc)
+    return out
+
+
 def bias_mish_pad(x_nhwc, bias, pad_h, pad_w):
     """Mish(x + bias) written into a new (B, H+pad_h, W+pad_w, C) tensor whose border is zero:
     the activation epilogue and TensorFlow's 'SAME' padding of the following stride-2 conv

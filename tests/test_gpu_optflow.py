@@ -234,3 +234,21 @@ def test_split_frames_pad():
     assert torch.equal(out[:3, :10, :12], x[..., :3]) and torch.equal(out[3:, :10, :12], x[..., 3:])
     assert float(out[:, 10].abs().max()) == 0.0 and float(out[:, :, 12].abs().max()) == 0.0
     assert torch.equal(ops.split_frames_pad(x.to(DEV)).cpu(), torch.cat([x[..., :3], x[..., 3:]], dim=0))
+
+
+@pytest.mark.parametrize("C", [16, 32])
+@pytest.mark.parametrize("hw,pad", [((16, 32), 0), ((19, 37), 0), ((24, 48), 1), ((9, 17), 1)])
+def test_conv3x3_mish_encoder_kernel(C, hw, pad):
+    """Encoder conv_aa / conv_b (3x3 'same' + bias + Mish, non_layers.py:410-449) on the matrix cores vs
+    torch's convolution; optional zero border = the next stride-2 conv's 'SAME' padding."""
+    rng = np.random.default_rng(C + hw[0] + pad)
+    H, W = hw
+    x = _rand(rng, 3, H, W, C)
+    w = _rand(rng, C, C, 3, 3) / np.sqrt(9 * C)
+    b = _rand(rng, C)
+    ref = torch_ref.mish(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1)
+    out = ops.conv3x3_mish(x.to(DEV), ops.conv3x3_taps(w.to(DEV)), b.to(DEV), pad, pad).cpu()
+    assert tuple(out.shape) == (3, H + pad, W + pad, C)
+    torch.testing.assert_close(out[:, :H, :W], ref, rtol=0, atol=2e-5)
+    if pad:
+        assert float(out[:, H:].abs().max()) == 0.0 and float(out[:, :, W:].abs().max()) == 0.0
