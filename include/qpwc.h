@@ -209,6 +209,14 @@ int qpwc_occlusion_fwd(const void* flow, void* out, int B, int H, int W, int lay
 int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,
                           int W, int C, int pad_h, int pad_w, void* stream);
 
+/* First encoder layer on the raw input pair: Split(2) (pwcnet.py:229) + both frames stacked on the
+ * batch axis (shared encoder weights, pwcnet.py:145-162) + enc.0.conv_a = Conv2D(3 -> 16, 3x3, stride 2,
+ * padding='same' [TensorFlow: 0 before, 1 after for even H, W], activation='Mish')
+ * (non_layers.py:402-409):  pairs (B,H,W,6) fp32, H and W even  ->  out (2B, H/2, W/2, 16), frame f of
+ * pair b at f*B + b.  weight: (9, 16, 4) fp32 = [ky*3+kx][out][in, slot 3 = 0]; bias (16). */
+int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,
+                             int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,78 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------
+// First encoder layer, enc.0.conv_a (Conv2D 3 -> 16, 3x3, stride 2, 'same', Mish; non_layers.py:402-409)
+// straight from the (B,H,W,6) input pair: Split(2) (pwcnet.py:229), the stacking of both frames on the
+// batch axis, TensorFlow's 'SAME' padding for even H, W (0 before, 1 after), the convolution, bias and
+// Mish in one launch -- the 25 MB input is read once and nothing but the 16-channel output is written.
+// K = 27: one v_mfma_f32_16x16x4_f32 per tap with k-slot g = input channel (slot 3 = 0).
+// Workgroup = 8 x 16 output pixels of BOTH frames (they share the staged 17 x 33 x 6 input patch);
+// wave w -> frame w >> 1, output rows 4 (w & 1) .. + 3.   weight: [9 taps][16 out][4] fp32 (slot 3 = 0).
+constexpr int kFcIH = 2 * kEcTH + 1, kFcIW = 2 * kEcTW + 1;   // 17 x 33 input pixels
+
+__global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int B, int H, int W,
+                                                                 int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float in_s[kFcIH * kFcIW * 6];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * kEcTH;           // output coordinates
+    const int Ho = H / 2, Wo = W / 2;
+    const float* xb = x + (int64_t)b * H * W * 6;
+    // ---- stage the input patch: rows 2 Y0 .. + 16, columns 2 X0 .. + 32, 6 channels (8-byte pieces) ----
+    for (int idx = tid; idx < kFcIH * kFcIW * 3; idx += 256) {
+        const int row = idx / (kFcIW * 3), e = idx - row * (kFcIW * 3);   // e = float2 index inside the row
+        const int gy = 2 * Y0 + row, gx = 2 * X0 + e / 3;
+        float2 v = make_float2(0.f, 0.f);
+        if (gy < H && gx < W) v = *reinterpret_cast<const float2*>(xb + ((int64_t)gy * W + 2 * X0) * 6 + 2 * e);
+        *reinterpret_cast<float2*>(in_s + row * (kFcIW * 6) + 2 * e) = v;
+    }
+    float wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = weight[(k * 16 + n) * 4 + g];   // W[tap][out n][channel g]
+    const float4 bq = *reinterpret_cast<const float4*>(bias + 4 * g);
+    __syncthreads();
+
+    const int f = wave >> 1;
+    float* ob = out + (int64_t)(f * B + b) * Ho * Wo * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = 4 * (wave & 1) + r;   // output row inside the tile
+        f32x4e acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float v = g < 3 ? in_s[((2 * oy + ky) * kFcIW + 2 * n + kx) * 6 + 3 * f + g] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx], v, acc, 0, 0, 0);
+            }
+        const int gy = Y0 + oy, gx = X0 + n;
+        if (gy < Ho && gx < Wo)
+            *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * 16 + 4 * g) =
+                make_float4(enc_mishf(acc[0] + bq.x), enc_mishf(acc[1] + bq.y), enc_mishf(acc[2] + bq.z),
+                            enc_mishf(acc[3] + bq.w));
+    }
+}
+
+int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                           hipStream_t s) {
+    const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + kEcTH - 1) / kEcTH;
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
+    if (nblk > INT32_MAX) {
+        set_error("first_conv_mish: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL(first_conv_mish_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const float*)x,
+                       (const float*)weight, (const float*)bias, (float*)out, B, H, W, tiles_x, tiles_y);
+    return check_launch("first_conv_mish_kernel");
+}
+
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s) {
     const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + kEcTH - 1) / kEcTH;

@@ -214,16 +214,20 @@ class DownConv(_Weighted):
     def __call__(self, x):
         return self.forward_padded(x)[0]
 
-    def forward_padded(self, x, padded_in=None, want_padded=False):
+    def forward_padded(self, x, padded_in=None, want_padded=False, after_a=None):
         """-> (features, padded).  `padded_in`: the input already carrying the (0,1) 'SAME'
         padding of the stride-2 conv (then `x` is ignored by conv_a).  `want_padded`: write
         the last activation into a (B,H+1,W+1,C) buffer with a zero border, so that the NEXT
-        DownConv needs no pad copy; `features` is then the interior view of that buffer."""
-        if padded_in is not None:
-            y = F.conv2d(self._nchw(padded_in), self.p("conv_a.weight"), None, stride=2)
+        DownConv needs no pad copy; `features` is then the interior view of that buffer.
+        `after_a`: Mish(conv_a(x) + bias) already computed (channels-last), conv_a is skipped."""
+        if after_a is not None:
+            y = after_a.permute(0, 3, 1, 2)
         else:
-            y = conv2d_same(self._nchw(x), self.p("conv_a.weight"), None, 2)
-        y = _bias_mish(y, self.p("conv_a.bias"), self.p32("conv_a.bias"), self.data_format)
+            if padded_in is not None:
+                y = F.conv2d(self._nchw(padded_in), self.p("conv_a.weight"), None, stride=2)
+            else:
+                y = conv2d_same(self._nchw(x), self.p("conv_a.weight"), None, 2)
+            y = _bias_mish(y, self.p("conv_a.bias"), self.p32("conv_a.bias"), self.data_format)
         h, w = y.shape[2], y.shape[3]
         pad_ok = want_padded and _same_pad(h, 3, 2) == (0, 1) and _same_pad(w, 3, 2) == (0, 1)
         if self._hip_conv_ok(y):
@@ -250,6 +254,20 @@ class DownConv(_Weighted):
     def _hip_conv_ok(self, y_nchw):
         return (self.hip_conv and y_nchw.dtype == torch.float32 and y_nchw.shape[1] in (16, 32) and
                 _hip_act_ok(y_nchw, self.data_format))
+
+    def first_layer(self, pairs):
+        """enc.0.conv_a on the raw (B,H,W,6) pair: split, frame stacking, 'SAME' padding, stride-2 conv,
+        bias and Mish in one HIP launch -> (2B, H/2, W/2, 16), or None when that kernel does not apply."""
+        w = self.p("conv_a.weight")
+        if not (self.hip_conv and self.data_format == CHANNELS_LAST and pairs.is_cuda and
+                pairs.dtype == torch.float32 and tuple(w.shape) == (16, 3, 3, 3) and
+                pairs.shape[1] % 2 == 0 and pairs.shape[2] % 2 == 0 and pairs.shape[3] == 6):
+            return None
+        key = self.prefix + "#taps_a"
+        t = self.params.get(key)
+        if t is None:
+            t = self.params[key] = ops.first_conv_taps(w)
+        return ops.first_conv_mish(pairs.contiguous(), t, self.p32("conv_a.bias"))
 
     def _taps(self):
         key = self.prefix + "#taps"

@@ -490,6 +490,33 @@ def conv3x3_mish(x_nhwc, taps, bias, pad_h=0, pad_w=0):
     return out
 
 
+def first_conv_taps(weight):
+    """torch Conv2d weight (16, 3, 3, 3) of enc.0.conv_a -> (9, 16, 4) fp32 [tap][out][in, slot 3 = 0]."""
+    w = weight.float().permute(2, 3, 0, 1).reshape(9, 16, 3)
+    out = torch.zeros((9, 16, 4), dtype=torch.float32, device=w.device)
+    out[..., :3] = w
+    return out
+
+
+def first_conv_mish(pairs, taps, bias):
+    """Split(2) + frame stacking + Conv2D(3->16, 3x3, stride 2, 'same') + bias + Mish of the first
+    encoder layer (pwcnet.py:229, non_layers.py:402-409) on the raw (B,H,W,6) fp32 input, H and W even
+    -> (2B, H/2, W/2, 16).  taps from first_conv_taps()."""
+    _check_tensor("pairs", pairs)
+    if pairs.shape[3] != 6 or pairs.dtype != torch.float32 or not pairs.is_contiguous():
+        raise ValueError("pairs must be a dense fp32 (B,H,W,6) tensor")
+    B, H, W, _ = pairs.shape
+    if tuple(taps.shape) != (9, 16, 4) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
+            bias.numel() != 16 or bias.dtype != torch.float32:
+        raise ValueError("taps must be fp32 (9,16,4), bias fp32 (16)")
+    out = torch.empty((2 * B, H // 2, W // 2, 16), dtype=torch.float32, device=pairs.device)
+    with torch.cuda.device(out.device), _timed("first_conv_mish", (B, H, W, 6)):
+        rc = _hip.lib().qpwc_first_conv_mish_fwd(pairs.data_ptr(), taps.data_ptr(), bias.data_ptr(),
+                                                 out.data_ptr(), B, H, W, _stream(out))
+    _hip.check(rc)
+    return out
+
+
 def bias_mish_pad(x_nhwc, bias, pad_h, pad_w):
     """Mish(x + bias) written into a new (B, H+pad_h, W+pad_w, C) tensor whose border is zero:
     the activation epilogue and TensorFlow's 'SAME' padding of the following stride-2 conv

@@ -150,7 +150,11 @@ class QpwcNet:
         """The encoder/decoder weights are shared by both frames (pwcnet.py:145-162, 179-206): run
         the encoder once on the 2B stacked frames [prv; nxt] -> [frames, enc_0 .. enc_4]."""
         h, w = self.input_shape
-        if (self.data_format == CHANNELS_LAST and inputs.is_cuda and h % 2 == 0 and w % 2 == 0 and
+        first = self.enc[0].first_layer(inputs)
+        if first is not None:
+            # the frames themselves (entry 0 of the reference's feature lists) are not used downstream
+            f, padded = inputs, None
+        elif (self.data_format == CHANNELS_LAST and inputs.is_cuda and h % 2 == 0 and w % 2 == 0 and
                 inputs.dtype in (torch.float32, torch.float16)):
             # split + stack + 'SAME' padding of the first stride-2 conv in one pass
             padded = ops.split_frames_pad(inputs, 1, 1)
@@ -160,7 +164,8 @@ class QpwcNet:
         encs = [f]
         for li, l in enumerate(self.enc):
             # the activation epilogue of level li lays down the 'SAME' padding level li+1 needs
-            f, padded = l.forward_padded(f, padded, want_padded=li + 1 < len(self.enc))
+            f, padded = l.forward_padded(f, padded, want_padded=li + 1 < len(self.enc),
+                                         after_a=first if li == 0 else None)
             encs.append(f)
         return encs
 

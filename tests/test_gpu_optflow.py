@@ -252,3 +252,19 @@ def test_conv3x3_mish_encoder_kernel(C, hw, pad):
     torch.testing.assert_close(out[:, :H, :W], ref, rtol=0, atol=2e-5)
     if pad:
         assert float(out[:, H:].abs().max()) == 0.0 and float(out[:, :, W:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hw", [(16, 32), (34, 50), (64, 128)])
+def test_first_conv_mish_on_raw_pairs(hw):
+    """enc.0.conv_a fused with Split(2), frame stacking and TF 'SAME' stride-2 padding vs torch."""
+    rng = np.random.default_rng(hw[0])
+    H, W = hw
+    pairs = _rand(rng, 3, H, W, 6)
+    w = _rand(rng, 16, 3, 3, 3) / np.sqrt(27)
+    b = _rand(rng, 16)
+    frames = torch.cat([pairs[..., :3], pairs[..., 3:]], dim=0).permute(0, 3, 1, 2)
+    ref = torch_ref.mish(torch.nn.functional.conv2d(torch.nn.functional.pad(frames, (0, 1, 0, 1)), w, b,
+                                                    stride=2)).permute(0, 2, 3, 1)
+    out = ops.first_conv_mish(pairs.to(DEV), ops.first_conv_taps(w.to(DEV)), b.to(DEV)).cpu()
+    assert tuple(out.shape) == (6, H // 2, W // 2, 16)
+    torch.testing.assert_close(out, ref, rtol=0, atol=2e-5)
