@@ -170,7 +170,7 @@ def main():
         dt = time.perf_counter() - t1
         serving = {"batches_in_flight": 2, "value": B * args.steps / dt, "unit": "pairs/s",
                    "ms_per_step": dt / args.steps * 1e3,
-                   "note": "two hipGraph replays (batch 8 each) on two streams; not the headline value"}
+                   "note": "two hipGraph replays (batch {} each) on two streams; not the headline value".format(B)}
         del g2
 
     # ---- live roofline of the dominant hot-path kernel: HIP events on the launch stream
