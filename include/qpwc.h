@@ -77,7 +77,10 @@ int qpwc_cost_volume_fwd(const void* prv, const void* nxt, void* out,
 /* Same computation, writing into a wider channels-last buffer: pixel p's d*d
  * results go to out + p*out_pixel_stride + out_channel_offset (in elements).
  * This is how Flow/UpFlow's concat([cost, prv, ...]) (non_layers.py:332-338,
- * 381-385) is fed without a copy.  NHWC only. */
+ * 381-385) is fed without a copy.  NHWC only.
+ * With out_pixel_stride == 84 and out_channel_offset == 0 the three pad channels 81..83 of every
+ * pixel are written as zeros: an 84-channel cost volume whose pixels start on 16-byte boundaries (the
+ * vector-load layout the fused SeparableConv2D consumes). */
 int qpwc_cost_volume_fwd_strided(const void* prv, const void* nxt, void* out,
                                  int B, int H, int W, int C, int search_range,
                                  int dtype, float lrelu_slope,

@@ -28,7 +28,7 @@ int check_launch(const char* what) {
 
 int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* out, int B, int H,
                        int W, int C, int r, int layout, int dtype, int64_t ops, float slope,
-                       bool fuse, hipStream_t s);
+                       bool fuse, bool pad84, hipStream_t s);
 int warp_launch(const void* img, const void* flo, void* out, int B, int H, int W, int C,
                 int flo_bcast_mask, int layout, int dtype, int mode, hipStream_t s);
 int epe_workspace_floats();
@@ -114,7 +114,9 @@ static int cost_volume_checked(const void* prv, const void* nxt, const void* flo
         (fuse && overlaps(out, n_out, flo, (size_t)B * H * W * 2 * 4)))
         return fail(QPWC_E_ALIAS, "out overlaps an input");
     char* o = (char*)out + (size_t)off * es;
-    return cost_volume_launch(prv, nxt, flo, o, B, H, W, C, r, layout, dtype, ops, slope, fuse,
+    // 84-float pixels holding the 81 channels at offset 0: the 3 pad channels are written as zeros
+    const bool pad84 = strided && !fuse && r == 4 && ops == 84 && off == 0;
+    return cost_volume_launch(prv, nxt, flo, o, B, H, W, C, r, layout, dtype, ops, slope, fuse, pad84,
                               (hipStream_t)stream);
 }
 

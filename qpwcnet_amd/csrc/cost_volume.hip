@@ -277,7 +277,16 @@ static int cost_volume_impl(const T* prv, const T* nxt, const float* flo, T* out
 }
 
 int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, int H, int W, int C,
-                            int dtype, int64_t ops, float slope, hipStream_t s);
+                            int dtype, int64_t ops, float slope, int pad84, bool* pads_written,
+                            hipStream_t s);
+
+// channels 81..83 of an 84-float pixel := 0 (see cost_volume_launch, pad84)
+template <typename T>
+__global__ __launch_bounds__(256) void zero_pads_kernel(T* __restrict__ out, int64_t n_pixels) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels * 3;
+         i += (int64_t)gridDim.x * blockDim.x)
+        st(out + (i / 3) * 84 + 81 + (i % 3), 0.0f);
+}
 
 // QPWC_CV_IMPL=valu forces the LDS-tiled vector kernel (A/B measurements only).
 static bool use_mfma() {
@@ -288,13 +297,29 @@ static bool use_mfma() {
     return v;
 }
 
+// pad84: the caller passes ops == 84 with channel offset 0 and wants channels 81..83 zeroed (an
+// 84-channel cost volume whose pixels are 16-byte aligned, for vector loads downstream).
 int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* out, int B, int H,
                        int W, int C, int r, int layout, int dtype, int64_t ops, float slope,
-                       bool fuse, hipStream_t s) {
+                       bool fuse, bool pad84, hipStream_t s) {
+    auto zero_pads = [&]() {
+        const int64_t npx = (int64_t)B * H * W;
+        const unsigned grid = (unsigned)((npx * 3 + 255) / 256 < 4096 ? (npx * 3 + 255) / 256 : 4096);
+        if (dtype == QPWC_F32)
+            hipLaunchKernelGGL(zero_pads_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)out, npx);
+        else
+            hipLaunchKernelGGL(zero_pads_kernel<__half>, dim3(grid), dim3(256), 0, s, (__half*)out, npx);
+    };
     if (!fuse && layout == QPWC_NHWC && r == 4 && use_mfma()) {
-        const int rc = cost_volume_mfma_launch(prv, nxt, out, B, H, W, C, dtype, ops, slope, s);
-        if (rc != 1) return rc;  // 1 = shape not eligible for the matrix-core path
+        bool pads_written = false;
+        const int rc = cost_volume_mfma_launch(prv, nxt, out, B, H, W, C, dtype, ops, slope, pad84 ? 1 : 0,
+                                               &pads_written, s);
+        if (rc != 1) {  // 1 = shape not eligible for the matrix-core path
+            if (rc == QPWC_OK && pad84 && !pads_written) zero_pads();
+            return rc;
+        }
     }
+    if (pad84) zero_pads();
     if (dtype == QPWC_F32)
         return cost_volume_impl<float>((const float*)prv, (const float*)nxt, (const float*)flo,
                                        (float*)out, B, H, W, C, r, layout, ops, slope, fuse, s);

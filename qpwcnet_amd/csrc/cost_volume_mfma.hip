@@ -55,36 +55,43 @@ constexpr int kRowStep = 4 * kFramePS + 12;   // frame offset of the next tile r
 struct FoffTable {
     unsigned short v[64][8];
 };
-constexpr FoffTable make_foff_table() {
+constexpr unsigned short kFoffPad = 0xffffu;   // element is one of the zero pads of an 84-wide pixel
+// S = floats per output pixel: 81 (dense) or 84 (81 channels + 3 zero pads: 16-byte aligned pixels)
+constexpr FoffTable make_foff_table(int S) {
     FoffTable t{};
     for (int lane = 0; lane < 64; ++lane)
         for (int it = 0; it < 2; ++it) {
             const int q = lane + 64 * it;
-            const int qq = q < 81 ? q : 0;
+            const int qq = q < S ? q : 0;
             for (int c = 0; c < 4; ++c) {
                 const int e = 4 * qq + c;
-                const int epx = e / 81, k = e - 81 * epx;
+                const int epx = e / S, k = e - S * epx;
                 const int ky = k / 9, kx = k - 9 * ky;
-                t.v[lane][4 * it + c] = (unsigned short)(4 * (epx * kFramePS + epx + ky * 12 + kx));
+                t.v[lane][4 * it + c] = k < 81 ? (unsigned short)(4 * (epx * kFramePS + epx + ky * 12 + kx)) : kFoffPad;
             }
         }
     return t;
 }
-__device__ const FoffTable kFoffTable = make_foff_table();
+__device__ const FoffTable kFoffTable = make_foff_table(81);
+__device__ const FoffTable kFoffTable84 = make_foff_table(84);
 
-__device__ __forceinline__ uint4 load_foff(int lane) {
-    return *reinterpret_cast<const uint4*>(&kFoffTable.v[lane][0]);
+__device__ __forceinline__ uint4 load_foff(int lane, int out_pix_stride = 81) {
+    return out_pix_stride == 84 ? *reinterpret_cast<const uint4*>(&kFoffTable84.v[lane][0])
+                                : *reinterpret_cast<const uint4*>(&kFoffTable.v[lane][0]);
 }
 
 // `tab` = load_foff(lane), fetched by the caller long before the epilogue.
 // Returns true when the dense path ran (exactly 8 store instructions per wave).
-template <typename T>
-__device__ __forceinline__ bool store_tile(const float* fr, T* ob, int lane, int x0, int y0, int H,
+template <typename T, bool PAD84>
+__device__ __forceinline__ bool store_tile_impl(const float* fr, T* ob, int lane, int x0, int y0, int H,
                                            int W, int out_pix_stride, float slope, float inv_c,
                                            float cf, uint4 tab) {
     const int row_stride = W * out_pix_stride;
-    if (out_pix_stride == 81 && (W & 3) == 0 && x0 + 4 <= W && y0 + 4 <= H &&
+    // dense rows: 4 px x 81 floats, or 4 px x 84 with the 3 pads of every pixel written as zeros (`tab`
+    // then comes from the 84-wide table; the caller asked for a zero-padded 84-channel volume)
+    if (out_pix_stride == (PAD84 ? 84 : 81) && (W & 3) == 0 && x0 + 4 <= W && y0 + 4 <= H &&
         (reinterpret_cast<uintptr_t>(ob) & (4 * sizeof(T) - 1)) == 0) {  // wave-uniform
+        constexpr bool padded = PAD84;
         // lane owns elements 4*q .. 4*q+3 of the 324-float row, q = lane (+64 for lanes 0..16)
         const unsigned tw[4] = {tab.x, tab.y, tab.z, tab.w};
         const char* frb = reinterpret_cast<const char*>(fr);
@@ -97,9 +104,12 @@ __device__ __forceinline__ bool store_tile(const float* fr, T* ob, int lane, int
                 for (int c = 0; c < 4; ++c) {
                     const unsigned w = tw[2 * it + (c >> 1)];
                     const unsigned off = (c & 1) ? (w >> 16) : (w & 0xffffu);
-                    v[row][it][c] = *reinterpret_cast<const float*>(frb + off + row * (kRowStep * 4));
+                    if (padded && off == kFoffPad)
+                        v[row][it][c] = 0.0f;
+                    else
+                        v[row][it][c] = *reinterpret_cast<const float*>(frb + off + row * (kRowStep * 4));
                 }
-        const bool second = lane < 17;  // float4 64..80
+        const bool second = lane < (padded ? 20 : 17);  // float4 64..80 (..83)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         auto emit = [&](auto act) {
 #pragma unroll
@@ -165,6 +175,15 @@ __device__ __forceinline__ bool store_tile(const float* fr, T* ob, int lane, int
         }
     }
     return false;
+}
+
+template <typename T>
+__device__ __forceinline__ bool store_tile(const float* fr, T* ob, int lane, int x0, int y0, int H, int W,
+                                           int out_pix_stride, float slope, float inv_c, float cf, uint4 tab,
+                                           bool pad84 = false) {
+    if (pad84)  // wave-uniform
+        return store_tile_impl<T, true>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, cf, tab);
+    return store_tile_impl<T, false>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, cf, tab);
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -256,7 +275,7 @@ struct OperandLoad<8, __half> {
 template <typename T, int CPL, int KS, int WPB>
 __global__ __launch_bounds__(64 * WPB, 4) void cost_volume_mfma_kernel(
     const T* __restrict__ prv, const T* __restrict__ nxt, T* __restrict__ out, int H, int W, int C,
-    int tiles_x, int tiles_y, int n_tiles, int out_pix_stride, float slope, float inv_c) {
+    int tiles_x, int tiles_y, int n_tiles, int out_pix_stride, float slope, float inv_c, int pad84) {
     constexpr int G = WPB / KS;       // tiles per workgroup
     constexpr int CSTEP = 4 * CPL;    // channels consumed per load step
     constexpr int ES = sizeof(T);
@@ -368,7 +387,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void cost_volume_mfma_kernel(
     const float* f0 = frames + grp * KS * kFrameFloats;
     T* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;  // scalar
     if (KS == 1) {  // the wave owns the whole frame: batched reads, 16-byte stores where possible
-        store_tile<T>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, cf, load_foff(lane));
+        store_tile<T>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, cf,
+                      load_foff(lane, pad84 ? 84 : 81), pad84 != 0);
         return;
     }
     const int row_stride = W * out_pix_stride;
@@ -418,7 +438,7 @@ constexpr int kRegLdsBytes = kRegStageBytes > 4 * kFrameFloats * 4 ? kRegStageBy
 
 __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     const float* __restrict__ prv, const float* __restrict__ nxt, float* __restrict__ out, int H, int W,
-    int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c) {
+    int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c, int pad84) {
     __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytes];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     const int lds_r = n * 128;  // + block*2048 + ((4u+g) ^ (n>>1))*16
     const int sw = n >> 1;
 
-    uint4 tab = load_foff(lane);  // epilogue offsets: in flight behind the first staging loads
+    uint4 tab = load_foff(lane, pad84 ? 84 : 81);  // epilogue offsets: in flight behind the first staging loads
     f32x4 acc[3][3];
     const int nsteps = C / 32;
     // one 32-channel step; FIRST: the accumulators start from the instruction's zero operand
@@ -520,7 +540,7 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
     if (x0 >= W || y0 >= H) return;
     float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
-    store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab);
+    store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab, pad84 != 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -535,7 +555,7 @@ constexpr int kRegLdsBytesH = kRegStageBytesH > 4 * kFrameFloats * 4 ? kRegStage
 
 __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
     const __half* __restrict__ prv, const __half* __restrict__ nxt, __half* __restrict__ out, int H,
-    int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c) {
+    int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c, int pad84) {
     __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytesH];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 tab = load_foff(lane);  // epilogue offsets, fetched early
+    uint4 tab = load_foff(lane, pad84 ? 84 : 81);  // epilogue offsets, fetched early
     const int nsteps = C / 32;
     for (int s = 0; s < nsteps; ++s) {
         const int soff = s * 64;
@@ -615,11 +635,11 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
     if (x0 >= W || y0 >= H) return;
     __half* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
-    store_tile<__half>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab);
+    store_tile<__half>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab, pad84 != 0);
 }
 
 static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int B, int H, int W, int C,
-                          int64_t ops, float slope, hipStream_t s) {
+                          int64_t ops, float slope, int pad84, hipStream_t s) {
     const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
     const int64_t nblk = (int64_t)regs_x * regs_y * B;
     if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * 2 >= 0x7fffffff ||
@@ -629,7 +649,7 @@ static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
     hipLaunchKernelGGL(cost_volume_mfma_lds_f16_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
-                       out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c);
+                       out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_lds_f16_kernel");
 }
 
@@ -648,7 +668,7 @@ static int lds_mode() {
 }
 
 static int launch_lds(const float* prv, const float* nxt, float* out, int B, int H, int W, int C,
-                      int64_t ops, float slope, hipStream_t s) {
+                      int64_t ops, float slope, int pad84, hipStream_t s) {
     const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
     const int64_t nblk = (int64_t)regs_x * regs_y * B;
     if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * 4 >= 0x7fffffff ||
@@ -664,13 +684,13 @@ static int launch_lds(const float* prv, const float* nxt, float* out, int B, int
     }
 #endif
     hipLaunchKernelGGL(cost_volume_mfma_lds_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
-                       H, W, C, regs_x, regs_y, (int)ops, slope, inv_c);
+                       H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_lds_kernel");
 }
 
 template <typename T, int CPL, int KS>
 static int launch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W, int C, int64_t ops,
-                       float slope, hipStream_t s) {
+                       float slope, int pad84, hipStream_t s) {
     constexpr int WPB = KS <= 4 ? 4 : KS;
     constexpr int G = WPB / KS;
     const int tiles_x = (W + 3) / 4, tiles_y = (H + 3) / 4;
@@ -684,30 +704,35 @@ static int launch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W, 
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;  // exact for powers of two
     hipLaunchKernelGGL((cost_volume_mfma_kernel<T, CPL, KS, WPB>), dim3((unsigned)nblk),
                        dim3(64 * WPB), 0, s, prv, nxt, out, H, W, C, tiles_x, tiles_y, (int)n_tiles,
-                       (int)ops, slope, inv_c);
+                       (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_kernel");
 }
 
 template <typename T, int CPL>
 static int dispatch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W, int C, int64_t ops,
-                         float slope, hipStream_t s) {
+                         float slope, int pad84, hipStream_t s) {
     const int64_t n_tiles = (int64_t)((W + 3) / 4) * ((H + 3) / 4) * B;
     const int nsteps = C / (4 * CPL);
     // enough waves for ~4 per SIMD on 1024 SIMDs; split channels when tiles are few
     int ks = 1;
     while (ks < 8 && n_tiles * ks < 4096 && nsteps % (ks * 2) == 0) ks *= 2;
     switch (ks) {
-        case 1: return launch_mfma<T, CPL, 1>(prv, nxt, out, B, H, W, C, ops, slope, s);
-        case 2: return launch_mfma<T, CPL, 2>(prv, nxt, out, B, H, W, C, ops, slope, s);
-        case 4: return launch_mfma<T, CPL, 4>(prv, nxt, out, B, H, W, C, ops, slope, s);
-        default: return launch_mfma<T, CPL, 8>(prv, nxt, out, B, H, W, C, ops, slope, s);
+        case 1: return launch_mfma<T, CPL, 1>(prv, nxt, out, B, H, W, C, ops, slope, pad84, s);
+        case 2: return launch_mfma<T, CPL, 2>(prv, nxt, out, B, H, W, C, ops, slope, pad84, s);
+        case 4: return launch_mfma<T, CPL, 4>(prv, nxt, out, B, H, W, C, ops, slope, pad84, s);
+        default: return launch_mfma<T, CPL, 8>(prv, nxt, out, B, H, W, C, ops, slope, pad84, s);
     }
 }
 
 // NHWC, search range 4, C % 16 == 0, 16-byte aligned operands.  Returns 1 if the
 // shape is not eligible (caller falls back to the LDS-tiled vector kernel).
+// pad84: `out` pixels are 84 floats apart and channels 81..83 are to be zero.  The dense epilogue
+// writes them itself; *pads_written says whether every tile of this launch takes that path (if not, the
+// caller zeroes the pads with its own small launch).
 int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, int H, int W, int C,
-                            int dtype, int64_t ops, float slope, hipStream_t s) {
+                            int dtype, int64_t ops, float slope, int pad84, bool* pads_written,
+                            hipStream_t s) {
+    if (pads_written) *pads_written = false;
     if (C % 16 != 0 || (reinterpret_cast<uintptr_t>(prv) | reinterpret_cast<uintptr_t>(nxt)) % 16)
         return 1;
     // 32-bit byte offsets inside one image (buffer descriptors) and 32-bit element offsets
@@ -720,20 +745,25 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
         // >= one region per CU: share the staged neighbourhood across a workgroup (L2 of the 256x512
         // pyramid, 256 regions x 4 steps: 10.2 us vs 11.8 us on the per-wave split-K kernel)
         if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 256 && lds_mode() != 0)
-            return launch_lds((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C, ops, slope, s);
+        {
+            // every tile dense: full 4x4 tiles, 16-byte aligned rows
+            if (pads_written)
+                *pads_written = pad84 && W % 4 == 0 && H % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+            return launch_lds((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C, ops, slope, pad84, s);
+        }
         if (C % 32 == 0)
             return dispatch_mfma<float, 8>((const float*)prv, (const float*)nxt, (float*)out, B, H, W,
-                                           C, ops, slope, s);
+                                           C, ops, slope, pad84, s);
         return dispatch_mfma<float, 4>((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C,
-                                       ops, slope, s);
+                                       ops, slope, pad84, s);
     }
     if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 256 && lds_mode() != 0)
-        return launch_lds_f16((const __half*)prv, (const __half*)nxt, (__half*)out, B, H, W, C, ops, slope, s);
+        return launch_lds_f16((const __half*)prv, (const __half*)nxt, (__half*)out, B, H, W, C, ops, slope, pad84, s);
     if (C % 32 == 0)
         return dispatch_mfma<__half, 8>((const __half*)prv, (const __half*)nxt, (__half*)out, B, H,
-                                        W, C, ops, slope, s);
+                                        W, C, ops, slope, pad84, s);
     return dispatch_mfma<__half, 4>((const __half*)prv, (const __half*)nxt, (__half*)out, B, H, W, C,
-                                    ops, slope, s);
+                                    ops, slope, pad84, s);
 }
 
 }  // namespace qpwc

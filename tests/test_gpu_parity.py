@@ -424,3 +424,27 @@ def test_cost_volume_output_only_element_aligned():
                                          _hip.NHWC, _hip.F32, 0.1, torch.cuda.current_stream().cuda_stream)
     _hip.check(rc)
     np.testing.assert_allclose(out.view(16, 64, 64, 81).cpu().numpy(), c_ref.cost_volume(prv, nxt), atol=TOL)
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 256, 32), (2, 64, 128, 64), (2, 16, 32, 256), (2, 8, 16, 256),
+                                   (2, 19, 37, 32), (1, 12, 20, 8)])
+def test_cost_volume_84_channel_padded_layout(shape):
+    """out_pixel_stride 84 at offset 0: channels 0..80 = the cost volume, 81..83 = 0 (16-byte aligned
+    pixels for vector consumers), whatever kernel path the shape takes and whatever the buffer held."""
+    g = torch.Generator(device=DEV).manual_seed(shape[1])
+    prv = torch.randn(*shape, device=DEV, generator=g)
+    nxt = torch.randn(*shape, device=DEV, generator=g)
+    dense = ops.cost_volume(prv, nxt)
+    buf = torch.full(shape[:3] + (84,), float("nan"), device=DEV)
+    ops.cost_volume_into(prv, nxt, buf, 0)
+    assert torch.equal(buf[..., :81], dense)
+    assert float(buf[..., 81:].abs().max()) == 0.0
+    # an 84-wide destination at a non-zero offset is an ordinary strided write: neighbours untouched
+    wide = torch.full(shape[:3] + (88,), 7.0, device=DEV)
+    ops.cost_volume_into(prv, nxt, wide, 4)
+    assert torch.equal(wide[..., 4:85], dense)
+    assert bool((wide[..., :4] == 7).all()) and bool((wide[..., 85:] == 7).all())
+    h = ops.cost_volume(prv.half(), nxt.half())
+    bh = torch.full(shape[:3] + (84,), float("nan"), device=DEV, dtype=torch.float16)
+    ops.cost_volume_into(prv.half(), nxt.half(), bh, 0)
+    assert torch.equal(bh[..., :81], h) and float(bh[..., 81:].abs().max()) == 0.0
