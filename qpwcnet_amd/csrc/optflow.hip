@@ -359,11 +359,41 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     auto fetch = [&](int c0) {   // global -> registers for the step starting at channel c0
         const int c = c0 + sch;
         if (VEC) {
-            const float* p = (const float*)src.ptr[0] + (int64_t)b * H * W * src.stride[0] + c;
+            // the quad of channels c..c+3 lies inside one source (every source but the last holds a
+            // multiple of 4 channels): 16-byte loads there, element loads for a short last source
+            // (Flow/UpFlow's 2-channel flow) -- the host checks alignment and strides
+            const float* p = nullptr;
+            int64_t ps = 0;
+            int left = 0;   // channels of the source from c on
+            if (c < C) {
+                int cc;
+                if (c < src.ch[0]) {
+                    p = (const float*)src.ptr[0]; ps = src.stride[0]; cc = c; left = src.ch[0] - c;
+                } else if (c < src.ch[0] + src.ch[1]) {
+                    p = (const float*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0]; left = src.ch[0] + src.ch[1] - c;
+                } else {
+                    p = (const float*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1]; left = C - c;
+                }
+                p += (int64_t)b * H * W * ps + cc;
+            }
+            if (left >= 4) {
 #pragma unroll
-            for (int it = 0; it < NST; ++it)
-                st4[it] = (goff[it] >= 0 && c < C) ? *reinterpret_cast<const float4*>(p + (int64_t)goff[it] * src.stride[0])
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int it = 0; it < NST; ++it)
+                    st4[it] = goff[it] >= 0 ? *reinterpret_cast<const float4*>(p + (int64_t)goff[it] * ps)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int it = 0; it < NST; ++it) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (goff[it] >= 0 && left > 0) {
+                        const float* q = p + (int64_t)goff[it] * ps;
+                        v.x = q[0];
+                        if (left > 1) v.y = q[1];
+                        if (left > 2) v.z = q[2];
+                    }
+                    st4[it] = v;
+                }
+            }
         }
         // (the generic multi-source path loads its inputs in commit(): 23 more live registers across
         // the depthwise and matrix phases would spill; the other workgroup of the CU covers the latency)
@@ -555,9 +585,15 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
         return QPWC_E_SHAPE;
     }
     const dim3 grid((unsigned)nblk);
-    // one dense source whose pixels are 16-byte aligned runs of a multiple of 4 channels: 16-byte loads
-    const bool vec = n_src == 1 && C % 4 == 0 && strides[0] % 4 == 0 &&
-                     reinterpret_cast<uintptr_t>(srcs[0]) % 16 == 0;
+    // 16-byte loads: every source but the last holds a multiple of 4 channels in 16-byte aligned
+    // pixels; the last one either does too or is read element-wise (it must not straddle a quad
+    // boundary with its predecessor, which the multiple-of-4 rule guarantees)
+    bool vec = true;
+    for (int i = 0; i < n_src; ++i) {
+        const bool aligned = chans[i] % 4 == 0 && strides[i] % 4 == 0 && reinterpret_cast<uintptr_t>(srcs[i]) % 16 == 0;
+        if (!aligned && i + 1 < n_src) vec = false;                  // only the last source may be odd
+        if (!aligned && i + 1 == n_src && chans[i] >= 4) vec = false; // ... and only if it is a short tail
+    }
     const float *fdw = (const float*)dw, *fpw = (const float*)pw, *fb = (const float*)bias;
     switch (F) {
         case 128: sepconv_dispatch<128>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;

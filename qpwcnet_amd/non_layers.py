@@ -314,11 +314,27 @@ class OptFlow(_Weighted):
             self._dw.append(dw.reshape(dw.shape[0], 9).float().contiguous())  # fp32 in every mode
         self._pw_pad = [ops.pad_pointwise(self.p("feat.{}.pointwise.weight".format(i)))
                         for i in range(len(self.filters))]
+        # first layer over [cost (81 + 3 zero pads) | ...]: the 84-channel cost volume keeps its pixels
+        # 16-byte aligned, the three pad channels get zero weights
+        if self._dw[0].shape[0] > 81:
+            pw0 = self.p("feat.0.pointwise.weight")
+            pw0 = pw0.reshape(pw0.shape[0], -1)
+            z = pw0.new_zeros((pw0.shape[0], 3))
+            pw84 = torch.cat([pw0[:, :81], z, pw0[:, 81:]], dim=1)
+            self._pw_t84 = pw84.t().contiguous()
+            self._pw_pad84 = ops.pad_pointwise(pw84)
+            self._dw84 = torch.cat([self._dw[0][:81], self._dw[0].new_zeros((3, 9)), self._dw[0][81:]]).contiguous()
         self._pw_b32 = [b.float().contiguous() for b in self._pw_b]
         self._head = pack_flow_head(self.p("conv.weight"), self.p("conv.bias"), self.p("norm.gamma"),
                                     self.p("norm.beta"), self.p("norm.mean"), self.p("norm.var"),
                                     self.BN_EPS, self.p("flow.weight"))
         self._hip_ready = True
+
+    def wants_cost84(self, prv):
+        """Flow/UpFlow ask: should the cost volume be produced as 84 channels (81 + 3 zero pads)?  Only
+        the fp32 fused SeparableConv2D profits (16-byte loads of all three sources)."""
+        return (self.data_format == CHANNELS_LAST and prv.is_cuda and prv.dtype == torch.float32 and
+                prv.shape[3] % 4 == 0 and self.filters[-1] == 16 and self.fused_sepconv is not False)
 
     def can_use_hip(self, sources):
         return (self.data_format == CHANNELS_LAST and self.filters[-1] == 16 and
@@ -344,19 +360,24 @@ class OptFlow(_Weighted):
                 return self._fuse_layer(self._dw[i].shape[0], n_tiles)
             return bool(self.fused_sepconv)
 
+        # an 84-channel first source = the zero-padded cost volume (Flow/UpFlow, wants_cost84)
+        padded_cost = sources[0].shape[3] == 84 and sum(t.shape[3] for t in sources) == self._dw[0].shape[0] + 3
         for i in range(n_layers):
             src = sources if i == 0 else [z]
             act_in = i > 0 and not z_act
+            first84 = i == 0 and padded_cost
+            dw_i = self._dw84 if first84 else self._dw[i]
             if fuse(i):  # depthwise + pointwise + bias in one launch, depthwise result stays on chip
                 # store Mish(z) when the next consumer is another fused layer (the flow head and the
                 # split depthwise kernel take pre-activation tensors and activate on load)
                 act_out = fuse(i + 1)
-                z = ops.sepconv3x3(src, self._dw[i], self._pw_pad[i], self._pw_b32[i], mish_on_load=act_in,
-                                   mish_on_store=act_out)
+                z = ops.sepconv3x3(src, dw_i, self._pw_pad84 if first84 else self._pw_pad[i], self._pw_b32[i],
+                                   mish_on_load=act_in, mish_on_store=act_out)
                 z_act = act_out
             else:
-                y = ops.dwconv3x3(src, self._dw[i], mish_on_load=act_in)
-                z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1), self._pw_t[i]).view(B, H, W, -1)
+                y = ops.dwconv3x3(src, dw_i, mish_on_load=act_in)
+                z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1),
+                                self._pw_t84 if first84 else self._pw_t[i]).view(B, H, W, -1)
                 z_act = False
         return ops.flow_head(z, self._head, scale)
 
@@ -402,11 +423,21 @@ class Flow(_Weighted):
 
     def __call__(self, inputs):
         prv, nxt = inputs
+        if self.hip_optflow and self.flow.wants_cost84(prv):
+            cost = self._cost84(prv, nxt)
+            return self.flow.from_sources((cost, prv, nxt))
         cost = self.cost_volume((prv, nxt))
         if self.hip_optflow:
             return self.flow.from_sources((cost, prv, nxt))
         feat = torch.cat([cost, prv, nxt], dim=self.axis)
         return self.flow(feat)
+
+
+    def _cost84(self, prv, nxt):
+        """The cost volume as (B,H,W,84): 81 channels + 3 zeros, pixels 16-byte aligned."""
+        cost = torch.empty(prv.shape[:3] + (84,), dtype=prv.dtype, device=prv.device)
+        ops.cost_volume_into(prv.contiguous(), nxt.contiguous(), cost, 0, self.cost_volume.search_range, 0.1)
+        return cost
 
 
 class UpFlow(_Weighted):
@@ -432,6 +463,9 @@ class UpFlow(_Weighted):
             feat = self._fused_feat(prv, nxt, flo)
             return self.flow(feat)
         nxt_w = self.warp((nxt, flo))
+        if self.hip_optflow and self.flow.wants_cost84(prv):
+            cost = Flow._cost84(self, prv, nxt_w)
+            return self.flow.from_sources((cost, prv, flo))
         cost = self.cost_volume((prv, nxt_w))
         if self.hip_optflow:
             return self.flow.from_sources((cost, prv, flo))

@@ -61,14 +61,21 @@ def main():
             # inside a fused chain the producer stores Mish(z): layers 2..4 load activated tensors
             # and layers 1..3 activate at the store
 
+            fsrcs, fdw, fpwp = srcs, dw, pwp
+            if li == 0:  # the network feeds layer 1 an 84-channel cost volume (81 + 3 zero pads)
+                z3 = torch.zeros(B, H, W, 3, device=dev)
+                fsrcs = [torch.cat([srcs[0], z3], dim=3)] + srcs[1:]
+                fdw = torch.cat([dw[:81], torch.zeros(3, 9, device=dev), dw[81:]]).contiguous()
+                fpwp = ops.pad_pointwise(torch.cat([pw[:, :81], torch.zeros(F, 3, device=dev), pw[:, 81:]], dim=1))
+
             def fused():
-                return ops.sepconv3x3(srcs, dw, pwp, bias, mish_on_load=False, mish_on_store=li < 3)
+                return ops.sepconv3x3(fsrcs, fdw, fpwp, bias, mish_on_load=False, mish_on_store=li < 3)
 
             def split():
                 y = ops.dwconv3x3(srcs, dw, mish_on_load=act)
                 return torch.addmm(bias, y.view(B * H * W, -1), pwt)
 
-            chk = ops.sepconv3x3(srcs, dw, pwp, bias, mish_on_load=act)
+            chk = ops.sepconv3x3(fsrcs, fdw, fpwp, bias, mish_on_load=act)
             err = float((chk.view(B * H * W, -1) - split()).abs().max())
             tf, ts = timeit(fused, a.iters), timeit(split, a.iters)
             flops = 2.0 * B * H * W * C * (F + 9)
