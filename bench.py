@@ -43,6 +43,8 @@ def parse_args():
     p.add_argument("--fused", dest="fused", action="store_true", default=False,
                    help="fused warp+cost-volume UpFlow front end")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-overlap", action="store_true",
+                   help="decoder and flow chain on one stream (A/B of the two-stream forward)")
     p.add_argument("--no-inflight", action="store_true",
                    help="skip the extra '2 batches in flight' throughput measurement (N=1 only)")
     p.add_argument("--dtype", default="f32", choices=["f32", "f16"],
@@ -102,6 +104,8 @@ def main():
     esize = 4 if args.dtype == "f32" else 2
     model = build_flower(True, hw, "channels_last", weights=weights, device=dev, fused=args.fused,
                          dtype=tdtype)
+    if args.no_overlap:
+        model.overlap_streams = False
     pairs_np, gt_np = synth.make_frames(B, hw[0], hw[1], seed=1234 + rank)
     pairs = torch.from_numpy(pairs_np).to(dev, tdtype)
     gt = torch.from_numpy(gt_np).to(dev)
@@ -186,7 +190,7 @@ def main():
         for _ in range(n_prof):
             forward()
     ktimes = kt.summary()
-    model.overlap_streams = True
+    model.overlap_streams = not args.no_overlap
     _, dom_ms_eager = ktimes[dom_key]
     dom_ms = dom_ms_eager
     if kt.captured is not None:
