@@ -220,6 +220,13 @@ int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, v
 int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,
                              int H, int W, void* stream);
 
+/* conv_a of the second encoder level: Conv2D(16 -> 32, 3x3, stride 2, padding='same', activation='Mish')
+ * (non_layers.py:402-409) on the zero-bordered output of qpwc_conv3x3_mish_fwd (pad 1, 1):
+ * x_padded (B, H+1, W+1, 16) fp32 with H, W even (row H and column W zero = TensorFlow's 'SAME' padding)
+ * -> out (B, H/2, W/2, 32).  weight: (9, 32, 16) fp32 = [ky*3+kx][out][in]; bias (32). */
+int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
+                            int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

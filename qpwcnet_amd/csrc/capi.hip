@@ -61,6 +61,8 @@ int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, voi
                         int C, int pad_h, int pad_w, hipStream_t s);
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                            hipStream_t s);
+int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                          hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
 
 static int fail(int code, const char* fmt, ...) {
@@ -398,6 +400,18 @@ int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* 
     if (overlaps(out, (size_t)2 * B * (H / 2) * (W / 2) * 16 * 4, pairs, (size_t)B * H * W * 6 * 4))
         return fail(QPWC_E_ALIAS, "out overlaps pairs");
     return first_conv_mish_launch(pairs, weight, bias, out, B, H, W, (hipStream_t)stream);
+}
+
+int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
+                            int H, int W, void* stream) {
+    if (!x_padded || !weight || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return fail(QPWC_E_SHAPE, "B=%d H=%d W=%d: H and W must be even and >= 2", B, H, W);
+    if ((uintptr_t)x_padded % 16 || (uintptr_t)weight % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
+        return fail(QPWC_E_ALIGN, "x, weight, bias, out must be 16-byte aligned");
+    if (overlaps(out, (size_t)B * (H / 2) * (W / 2) * 32 * 4, x_padded, (size_t)B * (H + 1) * (W + 1) * 16 * 4))
+        return fail(QPWC_E_ALIAS, "out overlaps x");
+    return conv3x3s2_mish_launch(x_padded, weight, bias, out, B, H, W, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -201,6 +201,100 @@ int first_conv_mish_launch(const void* x, const void* weight, const void* bias, 
     return check_launch("first_conv_mish_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// conv_a of the second encoder level: Conv2D(16 -> 32, 3x3, stride 2, 'same', Mish) (non_layers.py:402-409)
+// reading the zero-bordered (B, H+1, W+1, 16) output of the level before (the border IS TensorFlow's
+// 'SAME' padding for even H, W).  8 x 16 output pixels per workgroup; the 17 x 33 input patch is staged
+// with even and odd columns in separate planes, so that the three column taps of 16 neighbouring outputs
+// are 16 consecutive pixels of a plane (1 KB contiguous ds_read_b128).  Weights (9 taps x 2 output blocks)
+// stay in registers.   weight: [9][32 out][16 in] fp32; x pixel rows are Wp = W + 1 pixels long.
+constexpr int kS2IH = 2 * kEcTH + 1;      // 17 input rows
+constexpr int kS2PW = kEcTW + 1;          // 17 pixels per parity plane row (even: 17 used, odd: 16 used)
+
+__global__ __launch_bounds__(256, 4) void conv3x3s2_mish_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ weight,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ out, int H, int W,
+                                                                int tiles_x, int tiles_y) {
+    constexpr int CI = 16, CO = 32;
+    __shared__ __attribute__((aligned(16))) float in_s[2 * kS2IH * kS2PW * CI];   // [parity][row][col/2][16]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * kEcTH;   // output coordinates
+    const int Hp = H + 1, Wp = W + 1, Ho = H / 2, Wo = W / 2;
+    const float* xb = x + (int64_t)b * Hp * Wp * CI;
+    // ---- stage rows 2 Y0 .. + 16, columns 2 X0 .. + 32 (inside the padded input or zero) ----
+    for (int idx = tid; idx < kS2IH * 33 * 4; idx += 256) {
+        const int q = idx & 3, pxl = idx >> 2;
+        const int row = pxl / 33, col = pxl - row * 33;
+        const int gy = 2 * Y0 + row, gx = 2 * X0 + col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy < Hp && gx < Wp) v = *reinterpret_cast<const float4*>(xb + ((int64_t)gy * Wp + gx) * CI + 4 * q);
+        *reinterpret_cast<float4*>(in_s + (((col & 1) * kS2IH + row) * kS2PW + (col >> 1)) * CI + 4 * q) = v;
+    }
+    f32x4e wv[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+            wv[k][ft] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)k * CO + 16 * ft + n) * CI + 4 * g);
+    __syncthreads();
+
+    f32x4e acc[2][2];   // [tile row of this wave][output block]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) acc[m][ft] = f32x4e{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            f32x4e bv[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int row = 2 * (2 * wave + m) + ky;            // input row of output row 2 wave + m
+                const int par = kx & 1, pc = n + (kx >> 1);          // column 2 n + kx -> plane, index
+                bv[m] = *reinterpret_cast<const f32x4e*>(in_s + ((par * kS2IH + row) * kS2PW + pc) * CI + 4 * g);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+                        acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][ft][t], bv[m][t], acc[m][ft], 0, 0, 0);
+        }
+    float* ob = out + (int64_t)b * Ho * Wo * CO;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int gy = Y0 + 2 * wave + m, gx = X0 + n;
+            if (gy < Ho && gx < Wo)
+                *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * CO + 16 * ft + 4 * g) =
+                    make_float4(enc_mishf(acc[m][ft][0] + bq.x), enc_mishf(acc[m][ft][1] + bq.y),
+                                enc_mishf(acc[m][ft][2] + bq.z), enc_mishf(acc[m][ft][3] + bq.w));
+        }
+    }
+}
+
+int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                          hipStream_t s) {
+    const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + kEcTH - 1) / kEcTH;
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
+    if (nblk > INT32_MAX) {
+        set_error("conv3x3s2_mish: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL(conv3x3s2_mish_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const float*)x,
+                       (const float*)weight, (const float*)bias, (float*)out, H, W, tiles_x, tiles_y);
+    return check_launch("conv3x3s2_mish_kernel");
+}
+
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s) {
     const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + kEcTH - 1) / kEcTH;

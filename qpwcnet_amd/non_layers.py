@@ -220,6 +220,13 @@ class DownConv(_Weighted):
         the last activation into a (B,H+1,W+1,C) buffer with a zero border, so that the NEXT
         DownConv needs no pad copy; `features` is then the interior view of that buffer.
         `after_a`: Mish(conv_a(x) + bias) already computed (channels-last), conv_a is skipped."""
+        if after_a is None and padded_in is not None and self._hip_s2_ok(padded_in):
+            # second level: stride-2 conv + bias + Mish in one HIP launch on the zero-bordered input
+            key = self.prefix + "#taps_a"
+            t = self.params.get(key)
+            if t is None:
+                t = self.params[key] = ops.conv3x3_taps(self.p("conv_a.weight"))
+            after_a = ops.conv3x3s2_mish(padded_in, t, self.p32("conv_a.bias"))
         if after_a is not None:
             y = after_a.permute(0, 3, 1, 2)
         else:
@@ -250,6 +257,13 @@ class DownConv(_Weighted):
 
     # own 3x3 kernel for the levels where the library runs far below the matrix peak (16 / 32 channels)
     hip_conv = True
+
+    def _hip_s2_ok(self, padded_in):
+        w = self.p("conv_a.weight")
+        return (self.hip_conv and self.data_format == CHANNELS_LAST and padded_in.is_cuda and
+                padded_in.dtype == torch.float32 and padded_in.is_contiguous() and
+                tuple(w.shape) == (32, 16, 3, 3) and padded_in.shape[3] == 16 and
+                padded_in.shape[1] % 2 == 1 and padded_in.shape[2] % 2 == 1)
 
     def _hip_conv_ok(self, y_nchw):
         return (self.hip_conv and y_nchw.dtype == torch.float32 and y_nchw.shape[1] in (16, 32) and

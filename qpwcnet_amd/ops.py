@@ -517,6 +517,26 @@ def first_conv_mish(pairs, taps, bias):
     return out
 
 
+def conv3x3s2_mish(x_padded, taps, bias):
+    """Mish(conv3x3 stride 2 'same' (x) + bias), 16 -> 32 channels (the second encoder level's conv_a,
+    non_layers.py:402-409) on the zero-bordered (B, H+1, W+1, 16) fp32 tensor conv3x3_mish(pad 1, 1)
+    writes, H and W even -> (B, H/2, W/2, 32).  taps = conv3x3_taps(weight) of shape (9, 32, 16)."""
+    _check_tensor("x", x_padded)
+    if x_padded.dtype != torch.float32 or not x_padded.is_contiguous() or x_padded.shape[3] != 16:
+        raise ValueError("conv3x3s2_mish needs a dense fp32 (B,H+1,W+1,16) tensor")
+    B, Hp, Wp, _ = x_padded.shape
+    H, W = Hp - 1, Wp - 1
+    if tuple(taps.shape) != (9, 32, 16) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
+            bias.numel() != 32 or bias.dtype != torch.float32:
+        raise ValueError("taps must be fp32 (9,32,16), bias fp32 (32)")
+    out = torch.empty((B, H // 2, W // 2, 32), dtype=torch.float32, device=x_padded.device)
+    with torch.cuda.device(out.device), _timed("conv3x3s2_mish", (B, H, W, 16)):
+        rc = _hip.lib().qpwc_conv3x3s2_mish_fwd(x_padded.data_ptr(), taps.data_ptr(), bias.data_ptr(),
+                                                out.data_ptr(), B, H, W, _stream(out))
+    _hip.check(rc)
+    return out
+
+
 def bias_mish_pad(x_nhwc, bias, pad_h, pad_w):
     """Mish(x + bias) written into a new (B, H+pad_h, W+pad_w, C) tensor whose border is zero:
     the activation epilogue and TensorFlow's 'SAME' padding of the following stride-2 conv
