@@ -346,9 +346,16 @@ class OptFlow(_Weighted):
 
     def wants_cost84(self, prv):
         """Flow/UpFlow ask: should the cost volume be produced as 84 channels (81 + 3 zero pads)?  Only
-        the fp32 fused SeparableConv2D profits (16-byte loads of all three sources)."""
-        return (self.data_format == CHANNELS_LAST and prv.is_cuda and prv.dtype == torch.float32 and
-                prv.shape[3] % 4 == 0 and self.filters[-1] == 16 and self.fused_sepconv is not False)
+        a FUSED first layer profits (16-byte loads of all three sources); where it stays split (coarse
+        levels) the dense 81-channel volume avoids the extra pad-zeroing launch."""
+        if not (self.data_format == CHANNELS_LAST and prv.is_cuda and prv.dtype == torch.float32 and
+                prv.shape[3] % 4 == 0 and self.filters[-1] == 16 and self.fused_sepconv is not False):
+            return False
+        if self.fused_sepconv is True:
+            return True
+        B, H, W = prv.shape[:3]
+        self._prepare_hip()
+        return self._fuse_layer(self._dw[0].shape[0], B * ((H + 7) // 8) * ((W + 15) // 16))
 
     def can_use_hip(self, sources):
         return (self.data_format == CHANNELS_LAST and self.filters[-1] == 16 and
