@@ -55,7 +55,6 @@ constexpr int kRowStep = 4 * kFramePS + 12;   // frame offset of the next tile r
 struct FoffTable {
     unsigned short v[64][8];
 };
-constexpr unsigned short kFoffPad = 0xffffu;   // element is one of the zero pads of an 84-wide pixel
 // S = floats per output pixel: 81 (dense) or 84 (81 channels + 3 zero pads: 16-byte aligned pixels)
 constexpr FoffTable make_foff_table(int S) {
     FoffTable t{};
@@ -67,7 +66,12 @@ constexpr FoffTable make_foff_table(int S) {
                 const int e = 4 * qq + c;
                 const int epx = e / S, k = e - S * epx;
                 const int ky = k / 9, kx = k - 9 * ky;
-                t.v[lane][4 * it + c] = k < 81 ? (unsigned short)(4 * (epx * kFramePS + epx + ky * 12 + kx)) : kFoffPad;
+                // pads (k = 81..83: elements 1..3 of the float4 that starts at channel 80) read channel
+                // 80's frame entry and are zeroed after the read
+                const int kk = k < 81 ? k : 80;
+                const int kky = kk / 9, kkx = kk - 9 * kky;
+                (void)ky; (void)kx;
+                t.v[lane][4 * it + c] = (unsigned short)(4 * (epx * kFramePS + epx + kky * 12 + kkx));
             }
         }
     return t;
@@ -104,11 +108,19 @@ __device__ __forceinline__ bool store_tile_impl(const float* fr, T* ob, int lane
                 for (int c = 0; c < 4; ++c) {
                     const unsigned w = tw[2 * it + (c >> 1)];
                     const unsigned off = (c & 1) ? (w >> 16) : (w & 0xffffu);
-                    if (padded && off == kFoffPad)
-                        v[row][it][c] = 0.0f;
-                    else
-                        v[row][it][c] = *reinterpret_cast<const float*>(frb + off + row * (kRowStep * 4));
+                    v[row][it][c] = *reinterpret_cast<const float*>(frb + off + row * (kRowStep * 4));
                 }
+        if (padded) {
+            // float4 q of a row holds channels 80..83 of a pixel when q % 21 == 20: elements 1..3 are pads
+            const bool pad0 = lane % 21 == 20, pad1 = (lane + 64) % 21 == 20;
+#pragma unroll
+            for (int row = 0; row < 4; ++row)
+#pragma unroll
+                for (int c = 1; c < 4; ++c) {
+                    v[row][0][c] = pad0 ? 0.0f : v[row][0][c];
+                    v[row][1][c] = pad1 ? 0.0f : v[row][1][c];
+                }
+        }
         const bool second = lane < (padded ? 20 : 17);  // float4 64..80 (..83)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         auto emit = [&](auto act) {

@@ -133,7 +133,7 @@ def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST, lrelu_slope
     d = 2 * int(search_range) + 1
     buf, out = _empty_like_layout(p, dims, d * d, layout, as_view)
     if _TIMER is not None and _TIMER.capture == ("cost_volume",) + tuple(dims):
-        _TIMER.captured = (p, n)
+        _TIMER.captured = (p, n, d * d)
     with torch.cuda.device(p.device), _timed("cost_volume", dims):
         rc = _hip.lib().qpwc_cost_volume_fwd(
             p.data_ptr(), n.data_ptr(), buf.data_ptr(), B, H, W, C, int(search_range), layout,
@@ -203,6 +203,8 @@ def cost_volume_into(prv, nxt, out, channel_offset=0, search_range=4, lrelu_slop
     B, H, W, C = prv.shape
     if out.shape[:3] != prv.shape[:3]:
         raise ValueError("out must be (B,H,W,Ctot) with the image's B,H,W")
+    if flo is None and _TIMER is not None and _TIMER.capture == ("cost_volume", B, H, W, C):
+        _TIMER.captured = (prv, nxt, out.shape[3])   # inputs + pixel stride of the step's own launch
     L = _hip.lib()
     with torch.cuda.device(prv.device), \
             _timed("cost_volume" if flo is None else "warp_cost_volume", (B, H, W, C)):
