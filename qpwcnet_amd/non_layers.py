@@ -445,7 +445,7 @@ class Flow(_Weighted):
     def __call__(self, inputs):
         prv, nxt = inputs
         if self.hip_optflow and self.flow.wants_cost84(prv):
-            cost = self._cost84(prv, nxt)
+            cost = _cost84(prv, nxt, self.cost_volume.search_range)
             return self.flow.from_sources((cost, prv, nxt))
         cost = self.cost_volume((prv, nxt))
         if self.hip_optflow:
@@ -454,11 +454,12 @@ class Flow(_Weighted):
         return self.flow(feat)
 
 
-    def _cost84(self, prv, nxt):
-        """The cost volume as (B,H,W,84): 81 channels + 3 zeros, pixels 16-byte aligned."""
-        cost = torch.empty(prv.shape[:3] + (84,), dtype=prv.dtype, device=prv.device)
-        ops.cost_volume_into(prv.contiguous(), nxt.contiguous(), cost, 0, self.cost_volume.search_range, 0.1)
-        return cost
+def _cost84(prv, nxt, search_range):
+    """The cost volume as (B,H,W,84): 81 channels + 3 zeros, pixels 16-byte aligned (the layout the fused
+    first OptFlow layer reads with 16-byte loads)."""
+    cost = torch.empty(prv.shape[:3] + (84,), dtype=prv.dtype, device=prv.device)
+    ops.cost_volume_into(prv.contiguous(), nxt.contiguous(), cost, 0, search_range, 0.1)
+    return cost
 
 
 class UpFlow(_Weighted):
@@ -485,7 +486,7 @@ class UpFlow(_Weighted):
             return self.flow(feat)
         nxt_w = self.warp((nxt, flo))
         if self.hip_optflow and self.flow.wants_cost84(prv):
-            cost = Flow._cost84(self, prv, nxt_w)
+            cost = _cost84(prv, nxt_w, self.cost_volume.search_range)
             return self.flow.from_sources((cost, prv, flo))
         cost = self.cost_volume((prv, nxt_w))
         if self.hip_optflow:

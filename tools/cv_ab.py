@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""A/B helper: checks the cost volume at the L3/L4 shapes against the generic kernel path
-(QPWC_CV_IMPL is read once per process, so the reference comes from the C ABI with a search-range
-trick-free call on a crop) -- here simply against torch, then times it.  Env switches are read by
-the library at first use."""
+"""A/B harness for the cost-volume kernels: checks three shapes (L4, L3, a ragged one) against a torch
+restatement, then times 50 back-to-back launches five times.  The library reads its switches once per
+process, so run it once per variant:
+
+    python tools/cv_ab.py                                  # production build
+    QPWC_HIP_LIB=.../libqpwc_exp.so QPWC_CV_PIPE=1 python tools/cv_ab.py     # make -C qpwcnet_amd/csrc experimental
+    QPWC_STAMPS=1 ...                                      # also print the phase stamps of the experimental build
+"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qpwcnet_amd import ops
