@@ -178,3 +178,29 @@ def test_occlusion_host_errors():
         occlusion.get_spatial_shape(torch.zeros((5, 7, 2)), "channels_last")
     with pytest.raises(RuntimeError):
         occlusion.estimate_occlusion_map(torch.zeros((1, 5, 7, 2)), "channels_last")
+
+
+def test_keras_by_name_round_trip():
+    """by-name Keras layout <-> the flat torch-layout dict of build_flower."""
+    from qpwcnet_amd import weights as W
+    w = synth.make_weights(7, (64, 128))
+    names = W.keras_variable_names()
+    assert set(names) == set(w)                                   # every parameter has a Keras name
+    assert len(set(names.values())) == len(names)                 # ... and a distinct one
+    assert names["enc.0.conv_a.weight"] == "conv2d/kernel:0"
+    assert names["enc.4.conv_b.bias"] == "conv2d_14/bias:0"
+    assert names["dec.3.conv_up.weight"] == "conv2d_transpose_3/kernel:0"
+    assert names["flow.flow.feat.0.depthwise.weight"] == "separable_conv2d/depthwise_kernel:0"
+    assert names["flow.flow.conv.weight"] == "conv2d_15/kernel:0"
+    assert names["flow.flow.flow.weight"] == "conv2d_16/kernel:0"
+    assert names["upflow.3.flow.norm.var"] == "batch_normalization_4/moving_variance:0"
+    assert names["upflow.3.flow.flow.weight"] == "conv2d_24/kernel:0"
+    named = W.to_keras_named(w)
+    assert named["conv2d/kernel:0"].shape == (3, 3, 3, 16)        # (kh, kw, in, out)
+    assert named["conv2d_transpose/kernel:0"].shape == (4, 4, 128, 256)   # (kh, kw, out, in)
+    assert named["separable_conv2d/depthwise_kernel:0"].shape == (3, 3, 593, 1)
+    back = W.from_keras_named({"model_weights/" + k.split("/")[0] + "/" + k: v for k, v in named.items()})
+    assert set(back) == set(w) and all(np.array_equal(back[k], w[k]) for k in w)
+    del named["conv2d_3/bias:0"]
+    with pytest.raises(KeyError, match="conv2d_3/bias:0"):
+        W.from_keras_named(named)
