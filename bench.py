@@ -124,8 +124,14 @@ def main():
 
     graph = None
     if not args.no_graph:
-        graph = GraphedForward(model, pairs, epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=0)
-        flows, epe_local = graph.outputs, graph.extra
+        try:
+            graph = GraphedForward(model, pairs, epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=0)
+            flows, epe_local = graph.outputs, graph.extra
+        except RuntimeError as e:   # capture refused: keep measuring, with eager launches
+            print("bench.py: hipGraph capture failed ({}); eager launches".format(str(e).splitlines()[0]),
+                  file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
 
     def step():
         if graph is not None:
@@ -199,9 +205,15 @@ def main():
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
+        try:
+            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    for _ in range(n_rep):
+                        fn()
+            run = g.replay
+        except RuntimeError:   # capture refused (e.g. by another library's stream activity): eager replays
+            def run():
                 for _ in range(n_rep):
                     fn()
         torch.cuda.synchronize()
@@ -209,7 +221,7 @@ def main():
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            g.replay()
+            run()
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1) / n_rep

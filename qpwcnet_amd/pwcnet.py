@@ -231,7 +231,7 @@ class GraphedForward:
             run()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs, self.extra = run()
 
     def replay(self, inputs=None):

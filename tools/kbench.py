@@ -70,7 +70,7 @@ def main():
         for name, fn, _ in cases:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for _ in range(a.iters):
                         fn()
             graphs[name] = g

@@ -21,7 +21,7 @@ def timeit(fn, iters, rounds=5):
     side = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             for _ in range(iters):
                 fn()
     torch.cuda.synchronize()
