@@ -548,6 +548,219 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// fp16-storage form of the fused SeparableConv2D (BASELINE configs[4]): one dense source whose
+// pixels are 16-byte aligned runs of a multiple of 8 channels (OptFlow's layers 2..4), fp16 in and
+// out, the depthwise 3x3 in fp32 on the staged (and, on request, Mish-activated) tile, its result
+// rounded to fp16 -- the same rounding point as the depthwise kernel + fp16 GEMM it replaces -- and
+// the pointwise conv as ONE v_mfma_f32_16x16x32_f16 (fp32 accumulate) per accumulator and step.
+// y_s / w_s rows are 64 B (32 halves) with the 16-byte chunk c of row n at chunk c ^ ((n >> 2) & 2),
+// as in the fp16 cost volume.  pw: (F, Cpad) fp16, Cpad = ceil(C/32)*32; dw, bias fp32.
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+
+template <int F, bool ACT, bool ACT_OUT>
+__global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
+    const __half* __restrict__ src, int64_t src_stride, const float* __restrict__ dw,
+    const __half* __restrict__ pw, const float* __restrict__ bias, __half* __restrict__ out, int H, int W,
+    int C, int cpad, int tiles_x, int tiles_y) {
+    constexpr int NFT = F / 16;
+    constexpr int NST = 3;   // 180 halo pixels x 4 chunks of 8 channels / 256 threads
+    __shared__ __attribute__((aligned(16))) float in_s[kScNH * kScInPS];
+    __shared__ __attribute__((aligned(16))) __half y_s[kScTH * kScTW * kScKC];
+    __shared__ __attribute__((aligned(16))) __half w_s[F * kScKC];
+    __shared__ __attribute__((aligned(16))) float dw_s[9 * kScKC];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kScTW, Y0 = ty * kScTH;
+    const int n = lane & 15, g = lane >> 4;
+
+    f32x4v acc[2][NFT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < NFT; ++i) acc[m][i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // staging: 4 lanes x 16 B (8 channels) per halo pixel, 64 halo pixels per trip
+    const int soct = tid & 3, sps = tid >> 2;
+    int goff[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int hp = sps + 64 * it;
+        const int hy = hp / kScHW, hx = hp - hy * kScHW;
+        const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+        goff[it] = (hp < kScNH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    }
+    uint4 st[NST], wreg0, wreg1;
+    float dreg[2];
+    wreg0 = wreg1 = make_uint4(0, 0, 0, 0);
+    const __half* sb = src + (int64_t)b * H * W * src_stride;
+    auto fetch = [&](int c0) {
+        const int c = c0 + 8 * soct;
+#pragma unroll
+        for (int it = 0; it < NST; ++it)
+            st[it] = (goff[it] >= 0 && c < C) ? *reinterpret_cast<const uint4*>(sb + (int64_t)goff[it] * src_stride + c)
+                                              : make_uint4(0, 0, 0, 0);
+        {   // pointwise slice: F rows x 4 chunks of 16 B
+            const int f = tid >> 2, q = tid & 3;
+            const __half* wp = pw + (int64_t)f * cpad + c0 + 8 * q;
+            if (F >= 64 || f < F) wreg0 = *reinterpret_cast<const uint4*>(wp);
+            if (F >= 128) wreg1 = *reinterpret_cast<const uint4*>(wp + (int64_t)64 * cpad);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            dreg[i] = (idx < kScKC * 9 && c0 * 9 + idx < C * 9) ? dw[c0 * 9 + idx] : 0.0f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int hp = sps + 64 * it;
+            if (hp < kScNH) {
+                const __half2* h2 = reinterpret_cast<const __half2*>(&st[it]);
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float2 f2 = __half22float2(h2[k]);
+                    v[2 * k] = f2.x;
+                    v[2 * k + 1] = f2.y;
+                }
+                if (ACT && goff[it] >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = mishf(v[k]);
+                }
+                float* d = in_s + hp * kScInPS + 8 * soct;
+                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+        {
+            const int f = tid >> 2, q = tid & 3;
+            __half* wd = w_s + f * kScKC + ((q ^ (((f & 15) >> 2) & 2)) << 3);
+            if (F >= 64 || f < F) *reinterpret_cast<uint4*>(wd) = wreg0;
+            if (F >= 128) *reinterpret_cast<uint4*>(wd + 64 * kScKC) = wreg1;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < kScKC * 9) dw_s[(idx % 9) * kScKC + idx / 9] = dreg[i];
+        }
+    };
+
+    const int cq = tid & 7, strip = tid >> 3;
+    const int drow = strip >> 2, dxs = (strip & 3) * 4;
+    const int coff = n * kScKC + ((g ^ ((n >> 2) & 2)) << 3);   // halves: row n, chunk g (8 channels)
+
+    fetch(0);
+    for (int c0 = 0; c0 < cpad; c0 += kScKC) {
+        commit();
+        __syncthreads();
+        if (c0 + kScKC < cpad) fetch(c0 + kScKC);
+        {   // depthwise in fp32: 4 pixels x 4 channels per thread
+            float4 wq[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wq[k] = *reinterpret_cast<const float4*>(dw_s + k * kScKC + 4 * cq);
+            float4 a[4];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) a[px] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float4 r[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    r[j] = *reinterpret_cast<const float4*>(in_s + ((drow + ky) * kScHW + dxs + j) * kScInPS + 4 * cq);
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 v = r[px + kx];
+                        const float4 wk = wq[ky * 3 + kx];
+                        a[px].x = fmaf(wk.x, v.x, a[px].x);
+                        a[px].y = fmaf(wk.y, v.y, a[px].y);
+                        a[px].z = fmaf(wk.z, v.z, a[px].z);
+                        a[px].w = fmaf(wk.w, v.w, a[px].w);
+                    }
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {   // 4 halves = half a 16-byte chunk of the pixel's row
+                const int pix = drow * kScTW + dxs + px;
+                const int chunk = cq >> 1;
+                st4(y_s + pix * kScKC + ((chunk ^ (((pix & 15) >> 2) & 2)) << 3) + 4 * (cq & 1), a[px]);
+            }
+        }
+        __syncthreads();
+        {   // pointwise: one 16x16x32 matrix instruction per accumulator
+            f16x8v yv[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                yv[m] = *reinterpret_cast<const f16x8v*>(y_s + (32 * wave + 16 * m) * kScKC + coff);
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                const f16x8v wv = *reinterpret_cast<const f16x8v*>(w_s + 16 * ft * kScKC + coff);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, yv[m], acc[m][ft], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int pix = 32 * wave + 16 * m + n;
+        const int gy = Y0 + pix / kScTW, gx = X0 + pix % kScTW;
+        if (gy < H && gx < W) {
+            __half* o = out + ((int64_t)(b * H + gy) * W + gx) * F;
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+                float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
+                                       acc[m][ft][3] + bv.w);
+                if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
+                st4(o + 16 * ft + 4 * g, z);
+            }
+        }
+    }
+}
+
+template <int F>
+static void sepconv_f16_dispatch(const __half* src, int64_t stride, int act, const float* dw, const __half* pw,
+                                 const float* bias, __half* out, int H, int W, int C, int cpad, int tiles_x,
+                                 int tiles_y, dim3 grid, hipStream_t s) {
+#define QPWC_SCH_LAUNCH(ACT, AO)                                                                        \
+    hipLaunchKernelGGL((sepconv3x3_fused_f16_kernel<F, ACT, AO>), grid, dim3(256), 0, s, src, stride, dw, \
+                       pw, bias, out, H, W, C, cpad, tiles_x, tiles_y)
+    const bool in_act = (act & 1) != 0, out_act = (act & 2) != 0;
+    if (in_act) { if (out_act) QPWC_SCH_LAUNCH(true, true); else QPWC_SCH_LAUNCH(true, false); }
+    else        { if (out_act) QPWC_SCH_LAUNCH(false, true); else QPWC_SCH_LAUNCH(false, false); }
+#undef QPWC_SCH_LAUNCH
+}
+
+int sepconv3x3_f16_launch(const void* src, int C, int64_t stride, int act, const void* dw, const void* pw,
+                          const void* bias, void* out, int B, int H, int W, int F, hipStream_t s) {
+    const int cpad = (C + kScKC - 1) / kScKC * kScKC;
+    const int tiles_x = (W + kScTW - 1) / kScTW, tiles_y = (H + kScTH - 1) / kScTH;
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
+    if (nblk > INT32_MAX) {
+        set_error("sepconv3x3_f16: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    const dim3 grid((unsigned)nblk);
+    const __half* hs = (const __half*)src;
+    const __half* hp = (const __half*)pw;
+    const float *fdw = (const float*)dw, *fb = (const float*)bias;
+    switch (F) {
+        case 128: sepconv_f16_dispatch<128>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 64: sepconv_f16_dispatch<64>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 32: sepconv_f16_dispatch<32>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 16: sepconv_f16_dispatch<16>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        default: set_error("sepconv3x3_f16: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
+    }
+    return check_launch("sepconv3x3_fused_f16_kernel");
+}
+
 template <int F>
 static void sepconv_dispatch(const DwSrc& d, int act, bool vec, const float* dw, const float* pw,
                              const float* bias, float* out, int H, int W, int C, int cpad, int tiles_x,

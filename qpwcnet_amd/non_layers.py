@@ -328,6 +328,8 @@ class OptFlow(_Weighted):
             self._dw.append(dw.reshape(dw.shape[0], 9).float().contiguous())  # fp32 in every mode
         self._pw_pad = [ops.pad_pointwise(self.p("feat.{}.pointwise.weight".format(i)))
                         for i in range(len(self.filters))]
+        self._pw_pad16 = [ops.pad_pointwise(self.p("feat.{}.pointwise.weight".format(i)), torch.float16)
+                          for i in range(len(self.filters))]
         # first layer over [cost (81 + 3 zero pads) | ...]: the 84-channel cost volume keeps its pixels
         # 16-byte aligned, the three pad channels get zero weights
         if self._dw[0].shape[0] > 81:
@@ -375,8 +377,10 @@ class OptFlow(_Weighted):
         n_tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
 
         def fuse(i):
-            if not fp32 or i >= n_layers:
+            if i >= n_layers:
                 return False
+            if not fp32 and (i == 0 or self._dw[i].shape[0] % 8):
+                return False    # fp16: the single-source layers only (qpwc_sepconv3x3_f16_fwd)
             if self.fused_sepconv is None:
                 return self._fuse_layer(self._dw[i].shape[0], n_tiles)
             return bool(self.fused_sepconv)
@@ -392,8 +396,8 @@ class OptFlow(_Weighted):
                 # store Mish(z) when the next consumer is another fused layer (the flow head and the
                 # split depthwise kernel take pre-activation tensors and activate on load)
                 act_out = fuse(i + 1)
-                z = ops.sepconv3x3(src, dw_i, self._pw_pad84 if first84 else self._pw_pad[i], self._pw_b32[i],
-                                   mish_on_load=act_in, mish_on_store=act_out)
+                pw_i = self._pw_pad84 if first84 else (self._pw_pad[i] if fp32 else self._pw_pad16[i])
+                z = ops.sepconv3x3(src, dw_i, pw_i, self._pw_b32[i], mish_on_load=act_in, mish_on_store=act_out)
                 z_act = act_out
             else:
                 y = ops.dwconv3x3(src, dw_i, mish_on_load=act_in)

@@ -429,13 +429,13 @@ def _dw_sources(sources):
         B, H, W, sum(chans)
 
 
-def pad_pointwise(pw):
-    """(F, C[,1,1]) pointwise kernel -> dense fp32 (F, ceil(C/32)*32), zero padded: the
-    layout qpwc_sepconv3x3_fwd takes."""
-    pw = pw.reshape(pw.shape[0], -1).float()
+def pad_pointwise(pw, dtype=torch.float32):
+    """(F, C[,1,1]) pointwise kernel -> dense (F, ceil(C/32)*32), zero padded: the layout
+    qpwc_sepconv3x3_fwd (fp32) / qpwc_sepconv3x3_f16_fwd (fp16) takes."""
+    pw = pw.reshape(pw.shape[0], -1).to(dtype)
     F_, C = pw.shape
     cpad = (C + 31) // 32 * 32
-    out = torch.zeros((F_, cpad), dtype=torch.float32, device=pw.device)
+    out = torch.zeros((F_, cpad), dtype=dtype, device=pw.device)
     out[:, :C] = pw
     return out
 
@@ -447,21 +447,40 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False, mish_on_store=F
     -> (B,H,W,F): the pre-activation output, or Mish of it with mish_on_store (the layer's own
     `activation='Mish'` applied once per element; the consumer then loads without Mish)."""
     keep, c_ptrs, c_ch, c_st, B, H, W, C = _dw_sources(sources)
-    if keep[0].dtype != torch.float32:
-        raise ValueError("sepconv3x3 is fp32 only")
     F_ = pw_padded.shape[0]
     w = dw.reshape(-1, 9)
     if w.shape[0] != C or pw_padded.shape[1] != (C + 31) // 32 * 32 or bias.numel() != F_:
         raise ValueError("weight shapes do not match C = {}".format(C))
+    flags = int(bool(mish_on_load)) | (2 if mish_on_store else 0)
+    if keep[0].dtype == torch.float16:
+        return _sepconv3x3_f16(keep, w, pw_padded, bias, flags, B, H, W, C, F_)
+    if keep[0].dtype != torch.float32:
+        raise ValueError("sepconv3x3 takes fp32 or fp16 sources")
     for t in (w, pw_padded, bias):
         if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
             raise ValueError("weights must be dense fp32 device tensors")
     out = torch.empty((B, H, W, F_), dtype=torch.float32, device=keep[0].device)
     with torch.cuda.device(out.device), _timed("sepconv3x3", (B, H, W, C, F_)):
-        rc = _hip.lib().qpwc_sepconv3x3_fwd(c_ptrs, c_ch, c_st, len(keep),
-                                             int(bool(mish_on_load)) | (2 if mish_on_store else 0),
+        rc = _hip.lib().qpwc_sepconv3x3_fwd(c_ptrs, c_ch, c_st, len(keep), flags,
                                              w.data_ptr(), pw_padded.data_ptr(), bias.data_ptr(),
                                              out.data_ptr(), B, H, W, F_, _stream(out))
+    _hip.check(rc)
+    return out
+
+
+def _sepconv3x3_f16(keep, w, pw_padded, bias, flags, B, H, W, C, F_):
+    """fp16-storage form: one dense source, C % 8 == 0, pw_padded fp16 (qpwc_sepconv3x3_f16_fwd)."""
+    if len(keep) != 1 or C % 8 or keep[0].stride(2) % 8:
+        raise ValueError("fp16 sepconv3x3 takes one source of a multiple of 8 channels")
+    for t, dt in ((w, torch.float32), (pw_padded, torch.float16), (bias, torch.float32)):
+        if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("fp16 sepconv3x3: dw/bias dense fp32, pw dense fp16 device tensors")
+    x = keep[0]
+    out = torch.empty((B, H, W, F_), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(out.device), _timed("sepconv3x3_f16", (B, H, W, C, F_)):
+        rc = _hip.lib().qpwc_sepconv3x3_f16_fwd(x.data_ptr(), C, x.stride(2), flags, w.data_ptr(),
+                                                 pw_padded.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                 B, H, W, F_, _stream(out))
     _hip.check(rc)
     return out
 

@@ -183,6 +183,61 @@ def test_sepconv3x3_fused(chans, F, hw, act):
     torch.testing.assert_close(out_act, torch_ref.mish(ref), rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("C,F", [(128, 64), (64, 32), (32, 16), (40, 128), (8, 16)])
+@pytest.mark.parametrize("hw", [(8, 16), (19, 37)])
+@pytest.mark.parametrize("act", [False, True])
+def test_sepconv3x3_fused_fp16_storage(C, F, hw, act):
+    """qpwc_sepconv3x3_f16_fwd: fp16 in/out, fp32 depthwise rounded to fp16 once, f16 matrix cores with
+    fp32 accumulation.  Bound: the same rounding points restated on the oracle's ops (input and pointwise
+    weights fp16, depthwise result fp16) -> differences are accumulation order + the output rounding."""
+    rng = np.random.default_rng(C + F + hw[0])
+    H, W = hw
+    x = _rand(rng, 2, H, W, C).half()
+    dw = _rand(rng, C, 1, 3, 3)
+    pw = (_rand(rng, F, C, 1, 1) / np.sqrt(C)).half()
+    bias = _rand(rng, F)
+    y = torch_ref.depthwise3x3([x.float()], dw, act).half().float()
+    ref = torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw.float(), bias).permute(0, 2, 3, 1)
+    pw_pad = ops.pad_pointwise(pw.to(DEV), torch.float16)
+    out = ops.sepconv3x3([x.to(DEV)], dw.to(DEV), pw_pad, bias.to(DEV), mish_on_load=act)
+    assert out.dtype == torch.float16 and out.shape == ref.shape
+    # depthwise sums that land on an fp16 rounding boundary may round the other way (fma order)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=4e-3)
+    out_act = ops.sepconv3x3([x.to(DEV)], dw.to(DEV), pw_pad, bias.to(DEV), mish_on_load=act,
+                             mish_on_store=True)
+    torch.testing.assert_close(out_act.float().cpu(), torch_ref.mish(ref), rtol=2e-3, atol=4e-3)
+
+
+def test_sepconv3x3_fp16_rejects_unaligned_sources():
+    x = torch.zeros((1, 8, 16, 12), dtype=torch.float16, device=DEV)
+    dw = torch.zeros((12, 9), device=DEV)
+    pw = torch.zeros((16, 32), dtype=torch.float16, device=DEV)
+    with pytest.raises(ValueError):
+        ops.sepconv3x3([x], dw, pw, torch.zeros(16, device=DEV))
+    with pytest.raises(ValueError):   # fp32 pointwise weights with fp16 sources
+        ops.sepconv3x3([x[..., :8].contiguous()], dw[:8], pw.float(), torch.zeros(16, device=DEV))
+
+
+def test_optflow_fp16_fused_and_unfused_sepconv_agree():
+    hw = (32, 64)
+    weights = synth.make_weights(42, (256, 512))
+    rng = np.random.default_rng(7)
+    srcs = [t.half().to(DEV) for t in (_rand(rng, 2, *hw, 81), _rand(rng, 2, *hw, 128), _rand(rng, 2, *hw, 2))]
+    params = {k: torch.as_tensor(v).half().to(DEV) for k, v in weights.items()}
+    of = non_layers.OptFlow(params, "upflow.1.flow.", data_format="channels_last")
+    default = non_layers.OptFlow.fused_sepconv
+    try:
+        non_layers.OptFlow.fused_sepconv = True
+        a = of.from_sources(srcs).float().cpu()
+        non_layers.OptFlow.fused_sepconv = False
+        b = of.from_sources(srcs).float().cpu()
+    finally:
+        non_layers.OptFlow.fused_sepconv = default
+    scale = float(hw[0] ** 2 + hw[1] ** 2) ** 0.5
+    assert a.abs().max() > 0
+    torch.testing.assert_close(a / scale, b / scale, rtol=0, atol=3e-3)
+
+
 def test_optflow_fused_and_unfused_sepconv_agree():
     hw = (32, 64)
     weights = synth.make_weights(42, (256, 512))
