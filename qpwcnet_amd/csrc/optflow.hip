@@ -306,13 +306,20 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
 //             reads 2 + F/16 operands (ds_read_b128: k-slot g of a lane owns channels 4g..4g+3)
 //             for 8 x F/16 matrix instructions.  `y_s` / `w_s` rows are 128 B with the 16-byte
 //             chunk c of row n at chunk c ^ (n >> 1) (conflict free, as in the cost volume).
-// 62 KB LDS -> 2 workgroups per CU: while one is in its matrix phase the other stages/convolves.
+// Software pipeline: the matrix work of step k and the depthwise convolution of step k+1 share one
+// barrier interval (`y_s` double-buffered, inputs prefetched two steps ahead of their matrix work), two
+// barriers per step.  79 KB LDS -> 2 workgroups per CU.  Ablation at L4 (B=8, C 128 -> F 64, 80 us):
+// without the matrix instructions 54 us, without the global loads 67 us, without the depthwise
+// arithmetic 73 us -- the layer is as much bound by staging 200 MB through 2 waves per SIMD as by the
+// matrix pipe (31 us at its peak).
 // pointwise weights: (F, Cpad) row-major with Cpad = ceil(C/32)*32, zero padded.
 constexpr int kScKC = 32;               // channels per step
 constexpr int kScTH = 8, kScTW = 16;    // pixel tile
 constexpr int kScHH = kScTH + 2, kScHW = kScTW + 2;
 constexpr int kScNH = kScHH * kScHW;    // 180 halo pixels
 constexpr int kScInPS = 40;             // floats per halo pixel in in_s
+
+__device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <int F, bool ACT, bool VEC, bool ACT_OUT>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     constexpr int NFT = F / 16;
     constexpr int NST = VEC ? 6 : 23;   // staging loads per thread and step
     __shared__ __attribute__((aligned(16))) float in_s[kScNH * kScInPS];
-    __shared__ __attribute__((aligned(16))) float y_s[kScTH * kScTW * kScKC];
+    __shared__ __attribute__((aligned(16))) float y_s[2 * kScTH * kScTW * kScKC];
     __shared__ __attribute__((aligned(16))) float w_s[F * kScKC];
     __shared__ __attribute__((aligned(16))) float dw_s[9 * kScKC];
     const int tid = threadIdx.x;
@@ -356,37 +363,42 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     float4 wreg0, wreg1, wreg2, wreg3;   // F/32 of them in use (kept out of an array: no LDS promotion)
     float dreg[2];
     wreg0 = wreg1 = wreg2 = wreg3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int c0) {   // global -> registers for the step starting at channel c0
+    auto fetch_in = [&](int c0) {   // inputs + depthwise taps, global -> registers, step at channel c0
         const int c = c0 + sch;
         if (VEC) {
             // the quad of channels c..c+3 lies inside one source (every source but the last holds a
             // multiple of 4 channels): 16-byte loads there, element loads for a short last source
             // (Flow/UpFlow's 2-channel flow) -- the host checks alignment and strides
-            const float* p = nullptr;
-            int64_t ps = 0;
+            const float* p = kScZeros;
+            int ps = 0;
             int left = 0;   // channels of the source from c on
             if (c < C) {
                 int cc;
                 if (c < src.ch[0]) {
-                    p = (const float*)src.ptr[0]; ps = src.stride[0]; cc = c; left = src.ch[0] - c;
+                    p = (const float*)src.ptr[0]; ps = (int)src.stride[0]; cc = c; left = src.ch[0] - c;
                 } else if (c < src.ch[0] + src.ch[1]) {
-                    p = (const float*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0]; left = src.ch[0] + src.ch[1] - c;
+                    p = (const float*)src.ptr[1]; ps = (int)src.stride[1]; cc = c - src.ch[0]; left = src.ch[0] + src.ch[1] - c;
                 } else {
-                    p = (const float*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1]; left = C - c;
+                    p = (const float*)src.ptr[2]; ps = (int)src.stride[2]; cc = c - src.ch[0] - src.ch[1]; left = C - c;
                 }
                 p += (int64_t)b * H * W * ps + cc;
             }
-            if (left >= 4) {
+            if (left >= 4 || left == 0) {
+                // branch-free: halo pixels outside the image (and channels past C) read a 16-byte block of
+                // zeros; pixel offset x pixel stride is a 24-bit multiply (the launcher checks H*W < 2^24)
 #pragma unroll
-                for (int it = 0; it < NST; ++it)
-                    st4[it] = goff[it] >= 0 ? *reinterpret_cast<const float4*>(p + (int64_t)goff[it] * ps)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int it = 0; it < NST; ++it) {
+                    const bool ok = goff[it] >= 0 && left > 0;
+                    const float* q = ok ? p : kScZeros;
+                    const unsigned off = ok ? __umul24((unsigned)goff[it], (unsigned)ps) : 0u;
+                    st4[it] = *reinterpret_cast<const float4*>(q + off);
+                }
             } else {
 #pragma unroll
                 for (int it = 0; it < NST; ++it) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (goff[it] >= 0 && left > 0) {
-                        const float* q = p + (int64_t)goff[it] * ps;
+                    if (goff[it] >= 0) {
+                        const float* q = p + __umul24((unsigned)goff[it], (unsigned)ps);
                         v.x = q[0];
                         if (left > 1) v.y = q[1];
                         if (left > 2) v.z = q[2];
@@ -395,24 +407,24 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 }
             }
         }
-        // (the generic multi-source path loads its inputs in commit(): 23 more live registers across
-        // the depthwise and matrix phases would spill; the other workgroup of the CU covers the latency)
-        {   // pointwise slice: F rows x 8 chunks of 16 B, 256 chunks per trip
-            const float* wp = pw + (int64_t)(tid >> 3) * cpad + c0 + 4 * (tid & 7);
-            if (F >= 32 || (tid >> 3) < F) wreg0 = *reinterpret_cast<const float4*>(wp);
-            if (F >= 64) wreg1 = *reinterpret_cast<const float4*>(wp + (int64_t)32 * cpad);
-            if (F >= 128) {
-                wreg2 = *reinterpret_cast<const float4*>(wp + (int64_t)64 * cpad);
-                wreg3 = *reinterpret_cast<const float4*>(wp + (int64_t)96 * cpad);
-            }
-        }
+        // (the generic multi-source path loads its inputs in commit_in(): 23 more live registers across
+        // the depthwise and matrix work would spill; the other workgroup of the CU covers the latency)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {        // depthwise taps of the 32 channels: 288 floats
             const int idx = tid + 256 * i;
             dreg[i] = (idx < kScKC * 9 && c0 * 9 + idx < C * 9) ? dw[c0 * 9 + idx] : 0.0f;
         }
     };
-    auto commit = [&](int c0) {  // registers -> LDS
+    auto fetch_w = [&](int c0) {    // pointwise slice: F rows x 8 chunks of 16 B, 256 chunks per trip
+        const float* wp = pw + (int64_t)(tid >> 3) * cpad + c0 + 4 * (tid & 7);
+        if (F >= 32 || (tid >> 3) < F) wreg0 = *reinterpret_cast<const float4*>(wp);
+        if (F >= 64) wreg1 = *reinterpret_cast<const float4*>(wp + (int64_t)32 * cpad);
+        if (F >= 128) {
+            wreg2 = *reinterpret_cast<const float4*>(wp + (int64_t)64 * cpad);
+            wreg3 = *reinterpret_cast<const float4*>(wp + (int64_t)96 * cpad);
+        }
+    };
+    auto commit_in = [&](int c0) {  // registers -> in_s, dw_s
         if (VEC) {
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
@@ -447,20 +459,21 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 if (hp < kScNH) in_s[hp * kScInPS + sch] = (ACT && goff[it] >= 0) ? mishf(st[it]) : st[it];
             }
         }
-        {   // row f = tid>>3 (+32 i), chunk q = tid&7 at slot q ^ ((f & 15) >> 1); (f + 32 i) & 15 == f & 15
-            const int f = tid >> 3, q = tid & 7;
-            float* wd = w_s + f * kScKC + ((q ^ ((f & 15) >> 1)) << 2);
-            if (F >= 32 || f < F) *reinterpret_cast<float4*>(wd) = wreg0;
-            if (F >= 64) *reinterpret_cast<float4*>(wd + 32 * kScKC) = wreg1;
-            if (F >= 128) {
-                *reinterpret_cast<float4*>(wd + 64 * kScKC) = wreg2;
-                *reinterpret_cast<float4*>(wd + 96 * kScKC) = wreg3;
-            }
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;   // tap k of channel ch -> dw_s[k][ch]
             if (idx < kScKC * 9) dw_s[(idx % 9) * kScKC + idx / 9] = dreg[i];
+        }
+    };
+    auto commit_w = [&]() {
+        // row f = tid>>3 (+32 i), chunk q = tid&7 at slot q ^ ((f & 15) >> 1); (f + 32 i) & 15 == f & 15
+        const int f = tid >> 3, q = tid & 7;
+        float* wd = w_s + f * kScKC + ((q ^ ((f & 15) >> 1)) << 2);
+        if (F >= 32 || f < F) *reinterpret_cast<float4*>(wd) = wreg0;
+        if (F >= 64) *reinterpret_cast<float4*>(wd + 32 * kScKC) = wreg1;
+        if (F >= 128) {
+            *reinterpret_cast<float4*>(wd + 64 * kScKC) = wreg2;
+            *reinterpret_cast<float4*>(wd + 96 * kScKC) = wreg3;
         }
     };
 
@@ -470,51 +483,45 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     // ---- operand map of the matrix phase ----
     const int sw = n >> 1;
 
-    fetch(0);
-    for (int c0 = 0; c0 < cpad; c0 += kScKC) {
-        commit(c0);
-        __syncthreads();
-        if (c0 + kScKC < cpad) fetch(c0 + kScKC);
-        {   // depthwise
-            float4 wq[9];   // tap k of this thread's 4 channels
+    auto depthwise = [&](float* yd) {   // in_s -> yd
+        float4 wq[9];   // tap k of this thread's 4 channels
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wq[k] = *reinterpret_cast<const float4*>(dw_s + k * kScKC + 4 * cq);
-            float4 a[4];
+        for (int k = 0; k < 9; ++k) wq[k] = *reinterpret_cast<const float4*>(dw_s + k * kScKC + 4 * cq);
+        float4 a[4];
 #pragma unroll
-            for (int px = 0; px < 4; ++px) a[px] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int px = 0; px < 4; ++px) a[px] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                float4 r[6];
+        for (int ky = 0; ky < 3; ++ky) {
+            float4 r[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    r[j] = *reinterpret_cast<const float4*>(in_s + ((drow + ky) * kScHW + dxs + j) * kScInPS + 4 * cq);
+            for (int j = 0; j < 6; ++j)
+                r[j] = *reinterpret_cast<const float4*>(in_s + ((drow + ky) * kScHW + dxs + j) * kScInPS + 4 * cq);
 #pragma unroll
-                for (int px = 0; px < 4; ++px)
+            for (int px = 0; px < 4; ++px)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float4 v = r[px + kx];
-                        const float4 wk = wq[ky * 3 + kx];
-                        a[px].x = fmaf(wk.x, v.x, a[px].x);
-                        a[px].y = fmaf(wk.y, v.y, a[px].y);
-                        a[px].z = fmaf(wk.z, v.z, a[px].z);
-                        a[px].w = fmaf(wk.w, v.w, a[px].w);
-                    }
-            }
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const int pix = drow * kScTW + dxs + px;
-                *reinterpret_cast<float4*>(y_s + pix * kScKC + ((cq ^ ((pix & 15) >> 1)) << 2)) = a[px];
-            }
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 v = r[px + kx];
+                    const float4 wk = wq[ky * 3 + kx];
+                    a[px].x = fmaf(wk.x, v.x, a[px].x);
+                    a[px].y = fmaf(wk.y, v.y, a[px].y);
+                    a[px].z = fmaf(wk.z, v.z, a[px].z);
+                    a[px].w = fmaf(wk.w, v.w, a[px].w);
+                }
         }
-        __syncthreads();
-        // pointwise on the matrix cores: D[f][px] += W[f][k] * y[px][k]
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const int pix = drow * kScTW + dxs + px;
+            *reinterpret_cast<float4*>(yd + pix * kScKC + ((cq ^ ((pix & 15) >> 1)) << 2)) = a[px];
+        }
+    };
+    auto pointwise = [&](const float* ys) {   // D[f][px] += W[f][k] * y[px][k] on the matrix cores
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int coff = ((4 * u + g) ^ sw) << 2;
             f32x4v yv[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                yv[m] = *reinterpret_cast<const f32x4v*>(y_s + (32 * wave + 16 * m + n) * kScKC + coff);
+                yv[m] = *reinterpret_cast<const f32x4v*>(ys + (32 * wave + 16 * m + n) * kScKC + coff);
 #pragma unroll
             for (int ft = 0; ft < NFT; ++ft) {
                 const f32x4v wv = *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScKC + coff);
@@ -525,8 +532,45 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                         acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], yv[m][t], acc[m][ft], 0, 0, 0);
             }
         }
-        __syncthreads();  // in_s / w_s / y_s are rewritten by the next step
+    };
+
+    // Software pipeline: the matrix work of step k and the depthwise convolution of step k+1 sit in the
+    // same barrier interval (y_s double-buffered), so a wave's vector/LDS instructions issue behind its own
+    // matrix instructions instead of in a phase of their own.
+    //   A: y_s[k&1] complete, w_s and in_s free   -> commit weights(k), inputs(k+1)
+    //   B: staged                                 -> prefetch, pointwise(k) || depthwise(k+1)
+    const int nsteps = cpad / kScKC;
+    constexpr int kYs = kScTH * kScTW * kScKC;
+    fetch_in(0);
+    fetch_w(0);
+    commit_in(0);
+    __syncthreads();
+    if (nsteps > 1) fetch_in(kScKC);
+    depthwise(y_s);
+    for (int k = 0; k + 1 < nsteps; ++k) {
+        __syncthreads();
+        commit_w();
+        commit_in((k + 1) * kScKC);
+        __syncthreads();
+        fetch_w((k + 1) * kScKC);
+        if (k + 2 < nsteps) fetch_in((k + 2) * kScKC);
+        pointwise(y_s + (k & 1) * kYs);
+        depthwise(y_s + ((k + 1) & 1) * kYs);
+        // issue order: every matrix instruction (32 cycles in its pipe) followed by its share of the
+        // ~40 LDS reads and ~120 vector instructions of the depthwise convolution
+        constexpr int kNM = 16 * NFT;
+#pragma unroll
+        for (int i = 0; i < kNM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (40 + kNM - 1) / kNM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (120 + kNM - 1) / kNM, 0);
+        }
     }
+    __syncthreads();
+    commit_w();
+    __syncthreads();
+    asm volatile("; last step: matrix work only");
+    pointwise(y_s + ((nsteps - 1) & 1) * kYs);
     // ---- bias + store: lane = pixel n of a 16-pixel row segment, outputs 16 ft + 4 g .. + 3 ----
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -806,6 +850,9 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
         const bool aligned = chans[i] % 4 == 0 && strides[i] % 4 == 0 && reinterpret_cast<uintptr_t>(srcs[i]) % 16 == 0;
         if (!aligned && i + 1 < n_src) vec = false;                  // only the last source may be odd
         if (!aligned && i + 1 == n_src && chans[i] >= 4) vec = false; // ... and only if it is a short tail
+        // the 16-byte path multiplies pixel offset and pixel stride as 24-bit integers into 32 bits
+        if ((int64_t)H * W >= (1 << 24) || strides[i] >= (1 << 24) || (int64_t)H * W * strides[i] >= ((int64_t)1 << 32))
+            vec = false;
     }
     const float *fdw = (const float*)dw, *fpw = (const float*)pw, *fb = (const float*)bias;
     switch (F) {
