@@ -61,6 +61,22 @@ def cost_volume_bytes(B, H, W, C, esize=4):
     return B * H * W * (2 * C + 81) * esize
 
 
+def device_copy_ceiling(dev, mib=512, reps=10):
+    """GB/s (read + write bytes) of a dense device-to-device copy: the achievable HBM ceiling of this
+    box that SURVEY 8(d) asks to report beside the 8 TB/s nominal peak."""
+    src = torch.empty(mib << 20, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * src.numel() * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(weights, pairs_np, n_pairs, gpu_flows):
     """The reference-algorithm CPU restatement (oracle/net_ref.py; TF2 itself cannot run
     offline) on the host cores, on the first n_pairs of the same workload."""
@@ -186,6 +202,7 @@ def main():
     # ---- live roofline of the dominant hot-path kernel: HIP events on the launch stream
     # (single stream for this pass: with the decoder running beside it on the side stream the
     # events would time the kernel while it shares the chip)
+    copy_gbs = device_copy_ceiling(dev)
     n_prof = max(5, min(args.steps, 20))
     lvl4 = (B, hw[0] // 2, hw[1] // 2, synth.level_channels()[-1])
     dom_name = "warp_cost_volume" if args.fused else "cost_volume"
@@ -275,6 +292,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # the ceiling a plain device copy reaches on this box, measured now
+            "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
             "kernel": "{} L4 {}".format(dom_name, "x".join(map(str, lvl4))),
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
             "avg_launch_ms_inside_eager_step": dom_ms_eager,
