@@ -155,12 +155,14 @@ int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
                         int B, int H, int W, int F, void* stream);
 
 /* The same SeparableConv2D for fp16 storage (BASELINE configs[4], mixed_float16 in the reference's
- * train.py): ONE dense source of C channels (C % 8 == 0, pixels 16-byte aligned at
- * src_pixel_stride elements) -- OptFlow's layers 2..4 (non_layers.py:223-231).  src, out: fp16;
- * dw (C,3,3) and bias (F): fp32; pw: (F, Cpad) fp16, Cpad = ceil(C/32)*32, zero padded.  Depthwise in
- * fp32 on the fp16 input, rounded to fp16 once, pointwise on the f16 matrix cores with fp32
- * accumulation; mish_flags as above. */
-int qpwc_sepconv3x3_f16_fwd(const void* src, int C, int64_t src_pixel_stride, int mish_flags,
+ * train.py; non_layers.py:223-231): sources and `out` fp16, dw (C,3,3) and bias (F) fp32, pw (F, Cpad)
+ * fp16 with Cpad = ceil(C/32)*32, zero padded.  Depthwise in fp32 on the fp16 input, rounded to fp16
+ * once, pointwise on the f16 matrix cores with fp32 accumulation; mish_flags as above.  Sources as in
+ * qpwc_sepconv3x3_fwd, each a multiple of 4 channels in 8-byte aligned pixels (a last source of fewer
+ * than 4 channels is read element-wise); one dense source of C % 8 == 0 channels in 16-byte aligned
+ * pixels takes 16-byte loads. */
+int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels,
+                            const int64_t* src_pixel_stride, int n_src, int mish_flags,
                             const void* dw, const void* pw, const void* bias, void* out,
                             int B, int H, int W, int F, void* stream);
 

@@ -100,7 +100,7 @@ def lib():
     L.qpwc_sepconv3x3_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(i64),
                                       ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.qpwc_sepconv3x3_fwd.restype = ci
-    L.qpwc_sepconv3x3_f16_fwd.argtypes = [vp, ci, i64, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.qpwc_sepconv3x3_f16_fwd.argtypes = L.qpwc_sepconv3x3_fwd.argtypes
     L.qpwc_sepconv3x3_f16_fwd.restype = ci
     L.qpwc_bias_mish_pad_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, vp]
     L.qpwc_bias_mish_pad_fwd.restype = ci

@@ -41,8 +41,9 @@ int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* 
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
                      int act, const void* weight, void* out, int B, int H, int W, int dtype,
                      hipStream_t s);
-int sepconv3x3_f16_launch(const void* src, int C, int64_t stride, int act, const void* dw, const void* pw,
-                          const void* bias, void* out, int B, int H, int W, int F, hipStream_t s);
+int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src, int act,
+                          const void* dw, const void* pw, const void* bias, void* out, int B, int H, int W,
+                          int F, hipStream_t s);
 int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
                       int act, const void* dw, const void* pw, const void* bias, void* out, int B, int H,
                       int W, int F, hipStream_t s);
@@ -264,25 +265,34 @@ int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
                              H, W, F, (hipStream_t)stream);
 }
 
-int qpwc_sepconv3x3_f16_fwd(const void* src, int C, int64_t src_pixel_stride, int mish_flags, const void* dw,
-                            const void* pw, const void* bias, void* out, int B, int H, int W, int F,
-                            void* stream) {
-    if (!src || !dw || !pw || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels, const int64_t* src_pixel_stride,
+                            int n_src, int mish_flags, const void* dw, const void* pw, const void* bias,
+                            void* out, int B, int H, int W, int F, void* stream) {
+    if (!src || !src_channels || !src_pixel_stride || !dw || !pw || !bias || !out)
+        return fail(QPWC_E_NULL, "null pointer argument");
+    if (n_src < 1 || n_src > 3) return fail(QPWC_E_SHAPE, "n_src %d outside [1,3]", n_src);
     if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
     if (F != 16 && F != 32 && F != 64 && F != 128) return fail(QPWC_E_SHAPE, "F=%d not in {16,32,64,128}", F);
-    if (C <= 0 || C % 8) return fail(QPWC_E_SHAPE, "C=%d is not a positive multiple of 8", C);
-    if (src_pixel_stride < C || src_pixel_stride % 8)
-        return fail(QPWC_E_STRIDE, "%d channels at pixel stride %lld (must be a multiple of 8 >= C)", C,
-                    (long long)src_pixel_stride);
-    if ((uintptr_t)src % 16 || (uintptr_t)out % 16 || (uintptr_t)pw % 16 || (uintptr_t)bias % 16 ||
-        (uintptr_t)dw % 4)
-        return fail(QPWC_E_ALIGN, "src, out, pw, bias must be 16-byte aligned");
-    if (overlaps(out, (size_t)B * H * W * F * 2, src, (size_t)B * H * W * src_pixel_stride * 2))
-        return fail(QPWC_E_ALIAS, "out overlaps src");
-    if ((int64_t)H * W * src_pixel_stride > INT32_MAX) return fail(QPWC_E_SHAPE, "image too large");
+    for (int i = 0; i < n_src; ++i) {
+        if (!src[i]) return fail(QPWC_E_NULL, "null source %d", i);
+        if (src_channels[i] <= 0 || src_pixel_stride[i] < src_channels[i])
+            return fail(QPWC_E_STRIDE, "source %d: %d channels at pixel stride %lld", i, src_channels[i],
+                        (long long)src_pixel_stride[i]);
+        // 8-byte loads of 4 channels: every source but a short (< 4 channel) last one
+        const bool tail = i + 1 == n_src && src_channels[i] < 4;
+        if (!tail && (src_channels[i] % 4 || src_pixel_stride[i] % 4 || (uintptr_t)src[i] % 8))
+            return fail(QPWC_E_ALIGN, "source %d: %d channels at stride %lld must be multiples of 4, 8-byte aligned",
+                        i, src_channels[i], (long long)src_pixel_stride[i]);
+        if ((uintptr_t)src[i] % 2) return fail(QPWC_E_ALIGN, "source %d not element aligned", i);
+        if (overlaps(out, (size_t)B * H * W * F * 2, src[i], (size_t)B * H * W * src_pixel_stride[i] * 2))
+            return fail(QPWC_E_ALIAS, "out overlaps source %d", i);
+        if ((int64_t)H * W * src_pixel_stride[i] > INT32_MAX) return fail(QPWC_E_SHAPE, "image too large");
+    }
+    if ((uintptr_t)out % 16 || (uintptr_t)pw % 16 || (uintptr_t)bias % 16 || (uintptr_t)dw % 4)
+        return fail(QPWC_E_ALIGN, "out, pw, bias must be 16-byte aligned");
     if (mish_flags < 0 || mish_flags > 3) return fail(QPWC_E_SHAPE, "mish_flags %d outside [0,3]", mish_flags);
-    return sepconv3x3_f16_launch(src, C, src_pixel_stride, mish_flags, dw, pw, bias, out, B, H, W, F,
-                                 (hipStream_t)stream);
+    return sepconv3x3_f16_launch(src, src_channels, src_pixel_stride, n_src, mish_flags, dw, pw, bias, out, B,
+                                 H, W, F, (hipStream_t)stream);
 }
 
 int qpwc_flow_head_param_floats(void) { return flow_head_param_floats(); }

@@ -769,8 +769,11 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
         return dispatch_mfma<float, 4>((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C,
                                        ops, slope, pad84, s);
     }
-    if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 256 && lds_mode() != 0)
+    if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 256 && lds_mode() != 0) {
+        if (pads_written)   // dense 8-byte rows of 4 px x 84 halves
+            *pads_written = pad84 && W % 4 == 0 && H % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
         return launch_lds_f16((const __half*)prv, (const __half*)nxt, (__half*)out, B, H, W, C, ops, slope, pad84, s);
+    }
     if (C % 32 == 0)
         return dispatch_mfma<__half, 8>((const __half*)prv, (const __half*)nxt, (__half*)out, B, H,
                                         W, C, ops, slope, pad84, s);

@@ -602,13 +602,16 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 // as in the fp16 cost volume.  pw: (F, Cpad) fp16, Cpad = ceil(C/32)*32; dw, bias fp32.
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 
-template <int F, bool ACT, bool ACT_OUT>
+template <int F, bool ACT, bool ACT_OUT, bool WIDE>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
-    const __half* __restrict__ src, int64_t src_stride, const float* __restrict__ dw,
-    const __half* __restrict__ pw, const float* __restrict__ bias, __half* __restrict__ out, int H, int W,
-    int C, int cpad, int tiles_x, int tiles_y) {
+    DwSrc src, const float* __restrict__ dw, const __half* __restrict__ pw, const float* __restrict__ bias,
+    __half* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y) {
     constexpr int NFT = F / 16;
-    constexpr int NST = 3;   // 180 halo pixels x 4 chunks of 8 channels / 256 threads
+    // WIDE : one dense source, 4 lanes x 16 B (8 channels) per halo pixel, 64 halo pixels per trip
+    // else : up to three sources (virtual concat), 8 lanes x 8 B (4 channels) per pixel, 32 per trip;
+    //        every source but the last holds a multiple of 4 channels in 8-byte aligned pixels
+    constexpr int NST = WIDE ? 3 : 6;
+    constexpr int SPT = WIDE ? 64 : 32;
     __shared__ __attribute__((aligned(16))) float in_s[kScNH * kScInPS];
     __shared__ __attribute__((aligned(16))) __half y_s[kScTH * kScTW * kScKC];
     __shared__ __attribute__((aligned(16))) __half w_s[F * kScKC];
@@ -627,26 +630,62 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
 #pragma unroll
         for (int i = 0; i < NFT; ++i) acc[m][i] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    // staging: 4 lanes x 16 B (8 channels) per halo pixel, 64 halo pixels per trip
-    const int soct = tid & 3, sps = tid >> 2;
+    const int sch = WIDE ? 8 * (tid & 3) : 4 * (tid & 7);
+    const int sps = WIDE ? (tid >> 2) : (tid >> 3);
     int goff[NST];
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
-        const int hp = sps + 64 * it;
+        const int hp = sps + SPT * it;
         const int hy = hp / kScHW, hx = hp - hy * kScHW;
         const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
         goff[it] = (hp < kScNH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
     }
-    uint4 st[NST], wreg0, wreg1;
+    uint4 st[WIDE ? NST : 1], wreg0, wreg1;
+    uint2 st2[WIDE ? 1 : NST];
     float dreg[2];
     wreg0 = wreg1 = make_uint4(0, 0, 0, 0);
-    const __half* sb = src + (int64_t)b * H * W * src_stride;
     auto fetch = [&](int c0) {
-        const int c = c0 + 8 * soct;
+        const int c = c0 + sch;
+        if (WIDE) {
+            const __half* sb = (const __half*)src.ptr[0] + (int64_t)b * H * W * src.stride[0];
 #pragma unroll
-        for (int it = 0; it < NST; ++it)
-            st[it] = (goff[it] >= 0 && c < C) ? *reinterpret_cast<const uint4*>(sb + (int64_t)goff[it] * src_stride + c)
-                                              : make_uint4(0, 0, 0, 0);
+            for (int it = 0; it < NST; ++it)
+                st[it] = (goff[it] >= 0 && c < C)
+                             ? *reinterpret_cast<const uint4*>(sb + (int64_t)goff[it] * src.stride[0] + c)
+                             : make_uint4(0, 0, 0, 0);
+        } else {
+            const __half* p = nullptr;
+            int ps = 0, left = 0;   // channels of the source from c on
+            if (c < C) {
+                int cc;
+                if (c < src.ch[0]) {
+                    p = (const __half*)src.ptr[0]; ps = (int)src.stride[0]; cc = c; left = src.ch[0] - c;
+                } else if (c < src.ch[0] + src.ch[1]) {
+                    p = (const __half*)src.ptr[1]; ps = (int)src.stride[1]; cc = c - src.ch[0]; left = src.ch[0] + src.ch[1] - c;
+                } else {
+                    p = (const __half*)src.ptr[2]; ps = (int)src.stride[2]; cc = c - src.ch[0] - src.ch[1]; left = C - c;
+                }
+                p += (int64_t)b * H * W * ps + cc;
+            }
+            if (left >= 4) {
+#pragma unroll
+                for (int it = 0; it < NST; ++it)
+                    st2[it] = goff[it] >= 0 ? *reinterpret_cast<const uint2*>(p + (int64_t)goff[it] * ps)
+                                            : make_uint2(0, 0);
+            } else {   // short last source (Flow/UpFlow's 2-channel flow): element loads
+#pragma unroll
+                for (int it = 0; it < NST; ++it) {
+                    unsigned short h[4] = {0, 0, 0, 0};
+                    if (goff[it] >= 0 && left > 0) {
+                        const unsigned short* q = reinterpret_cast<const unsigned short*>(p + (int64_t)goff[it] * ps);
+                        h[0] = q[0];
+                        if (left > 1) h[1] = q[1];
+                        if (left > 2) h[2] = q[2];
+                    }
+                    st2[it] = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                }
+            }
+        }
         {   // pointwise slice: F rows x 4 chunks of 16 B
             const int f = tid >> 2, q = tid & 3;
             const __half* wp = pw + (int64_t)f * cpad + c0 + 8 * q;
@@ -662,23 +701,25 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     auto commit = [&]() {
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
-            const int hp = sps + 64 * it;
+            const int hp = sps + SPT * it;
             if (hp < kScNH) {
-                const __half2* h2 = reinterpret_cast<const __half2*>(&st[it]);
-                float v[8];
+                constexpr int NV = WIDE ? 8 : 4;
+                const __half2* h2 = WIDE ? reinterpret_cast<const __half2*>(&st[WIDE ? it : 0])
+                                         : reinterpret_cast<const __half2*>(&st2[WIDE ? 0 : it]);
+                float v[NV];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NV / 2; ++k) {
                     const float2 f2 = __half22float2(h2[k]);
                     v[2 * k] = f2.x;
                     v[2 * k + 1] = f2.y;
                 }
                 if (ACT && goff[it] >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = mishf(v[k]);
+                    for (int k = 0; k < NV; ++k) v[k] = mishf(v[k]);
                 }
-                float* d = in_s + hp * kScInPS + 8 * soct;
+                float* d = in_s + hp * kScInPS + sch;
                 *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (WIDE) *reinterpret_cast<float4*>(d + 4) = make_float4(v[NV - 4], v[NV - 3], v[NV - 2], v[NV - 1]);
             }
         }
         {
@@ -770,20 +811,37 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
 }
 
 template <int F>
-static void sepconv_f16_dispatch(const __half* src, int64_t stride, int act, const float* dw, const __half* pw,
+static void sepconv_f16_dispatch(const DwSrc& d, bool wide, int act, const float* dw, const __half* pw,
                                  const float* bias, __half* out, int H, int W, int C, int cpad, int tiles_x,
                                  int tiles_y, dim3 grid, hipStream_t s) {
-#define QPWC_SCH_LAUNCH(ACT, AO)                                                                        \
-    hipLaunchKernelGGL((sepconv3x3_fused_f16_kernel<F, ACT, AO>), grid, dim3(256), 0, s, src, stride, dw, \
-                       pw, bias, out, H, W, C, cpad, tiles_x, tiles_y)
+#define QPWC_SCH_LAUNCH(ACT, AO, WD)                                                                        \
+    hipLaunchKernelGGL((sepconv3x3_fused_f16_kernel<F, ACT, AO, WD>), grid, dim3(256), 0, s, d, dw, pw, bias, \
+                       out, H, W, C, cpad, tiles_x, tiles_y)
     const bool in_act = (act & 1) != 0, out_act = (act & 2) != 0;
-    if (in_act) { if (out_act) QPWC_SCH_LAUNCH(true, true); else QPWC_SCH_LAUNCH(true, false); }
-    else        { if (out_act) QPWC_SCH_LAUNCH(false, true); else QPWC_SCH_LAUNCH(false, false); }
+    if (wide) {
+        if (in_act) { if (out_act) QPWC_SCH_LAUNCH(true, true, true); else QPWC_SCH_LAUNCH(true, false, true); }
+        else        { if (out_act) QPWC_SCH_LAUNCH(false, true, true); else QPWC_SCH_LAUNCH(false, false, true); }
+    } else {
+        if (in_act) { if (out_act) QPWC_SCH_LAUNCH(true, true, false); else QPWC_SCH_LAUNCH(true, false, false); }
+        else        { if (out_act) QPWC_SCH_LAUNCH(false, true, false); else QPWC_SCH_LAUNCH(false, false, false); }
+    }
 #undef QPWC_SCH_LAUNCH
 }
 
-int sepconv3x3_f16_launch(const void* src, int C, int64_t stride, int act, const void* dw, const void* pw,
-                          const void* bias, void* out, int B, int H, int W, int F, hipStream_t s) {
+// wide (16-byte loads): one source, C % 8 == 0, pixel stride % 8 == 0, 16-byte aligned base;
+// otherwise 8-byte loads over up to three sources -- the capi checks what each form requires
+int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src, int act,
+                          const void* dw, const void* pw, const void* bias, void* out, int B, int H, int W,
+                          int F, hipStream_t s) {
+    DwSrc d;
+    int C = 0;
+    for (int i = 0; i < 3; ++i) {
+        d.ptr[i] = i < n_src ? srcs[i] : nullptr;
+        d.ch[i] = i < n_src ? chans[i] : 0;
+        d.stride[i] = i < n_src ? strides[i] : 0;
+        C += d.ch[i];
+    }
+    const bool wide = n_src == 1 && C % 8 == 0 && strides[0] % 8 == 0 && reinterpret_cast<uintptr_t>(srcs[0]) % 16 == 0;
     const int cpad = (C + kScKC - 1) / kScKC * kScKC;
     const int tiles_x = (W + kScTW - 1) / kScTW, tiles_y = (H + kScTH - 1) / kScTH;
     const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
@@ -792,14 +850,13 @@ int sepconv3x3_f16_launch(const void* src, int C, int64_t stride, int act, const
         return QPWC_E_SHAPE;
     }
     const dim3 grid((unsigned)nblk);
-    const __half* hs = (const __half*)src;
     const __half* hp = (const __half*)pw;
     const float *fdw = (const float*)dw, *fb = (const float*)bias;
     switch (F) {
-        case 128: sepconv_f16_dispatch<128>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 64: sepconv_f16_dispatch<64>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 32: sepconv_f16_dispatch<32>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 16: sepconv_f16_dispatch<16>(hs, stride, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 128: sepconv_f16_dispatch<128>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 64: sepconv_f16_dispatch<64>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 32: sepconv_f16_dispatch<32>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+        case 16: sepconv_f16_dispatch<16>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
         default: set_error("sepconv3x3_f16: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
     }
     return check_launch("sepconv3x3_fused_f16_kernel");

@@ -339,6 +339,7 @@ class OptFlow(_Weighted):
             pw84 = torch.cat([pw0[:, :81], z, pw0[:, 81:]], dim=1)
             self._pw_t84 = pw84.t().contiguous()
             self._pw_pad84 = ops.pad_pointwise(pw84)
+            self._pw_pad84_16 = ops.pad_pointwise(pw84, torch.float16)
             self._dw84 = torch.cat([self._dw[0][:81], self._dw[0].new_zeros((3, 9)), self._dw[0][81:]]).contiguous()
         self._pw_b32 = [b.float().contiguous() for b in self._pw_b]
         self._head = pack_flow_head(self.p("conv.weight"), self.p("conv.bias"), self.p("norm.gamma"),
@@ -350,7 +351,7 @@ class OptFlow(_Weighted):
         """Flow/UpFlow ask: should the cost volume be produced as 84 channels (81 + 3 zero pads)?  Only
         a FUSED first layer profits (16-byte loads of all three sources); where it stays split (coarse
         levels) the dense 81-channel volume avoids the extra pad-zeroing launch."""
-        if not (self.data_format == CHANNELS_LAST and prv.is_cuda and prv.dtype == torch.float32 and
+        if not (self.data_format == CHANNELS_LAST and prv.is_cuda and prv.dtype in (torch.float32, torch.float16) and
                 prv.shape[3] % 4 == 0 and self.filters[-1] == 16 and self.fused_sepconv is not False):
             return False
         if self.fused_sepconv is True:
@@ -375,18 +376,18 @@ class OptFlow(_Weighted):
         fp32 = sources[0].dtype == torch.float32
         n_layers = len(self.filters)
         n_tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
+        # an 84-channel first source = the zero-padded cost volume (Flow/UpFlow, wants_cost84)
+        padded_cost = sources[0].shape[3] == 84 and sum(t.shape[3] for t in sources) == self._dw[0].shape[0] + 3
 
         def fuse(i):
             if i >= n_layers:
                 return False
-            if not fp32 and (i == 0 or self._dw[i].shape[0] % 8):
-                return False    # fp16: the single-source layers only (qpwc_sepconv3x3_f16_fwd)
+            if not fp32 and (self._dw[i].shape[0] % 4 if i else not padded_cost):
+                return False    # fp16 (qpwc_sepconv3x3_f16_fwd): sources in 8-byte aligned runs of 4 channels
             if self.fused_sepconv is None:
                 return self._fuse_layer(self._dw[i].shape[0], n_tiles)
             return bool(self.fused_sepconv)
 
-        # an 84-channel first source = the zero-padded cost volume (Flow/UpFlow, wants_cost84)
-        padded_cost = sources[0].shape[3] == 84 and sum(t.shape[3] for t in sources) == self._dw[0].shape[0] + 3
         for i in range(n_layers):
             src = sources if i == 0 else [z]
             act_in = i > 0 and not z_act
@@ -396,7 +397,10 @@ class OptFlow(_Weighted):
                 # store Mish(z) when the next consumer is another fused layer (the flow head and the
                 # split depthwise kernel take pre-activation tensors and activate on load)
                 act_out = fuse(i + 1)
-                pw_i = self._pw_pad84 if first84 else (self._pw_pad[i] if fp32 else self._pw_pad16[i])
+                if fp32:
+                    pw_i = self._pw_pad84 if first84 else self._pw_pad[i]
+                else:
+                    pw_i = self._pw_pad84_16 if first84 else self._pw_pad16[i]
                 z = ops.sepconv3x3(src, dw_i, pw_i, self._pw_b32[i], mish_on_load=act_in, mish_on_store=act_out)
                 z_act = act_out
             else:

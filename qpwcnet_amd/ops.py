@@ -453,7 +453,7 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False, mish_on_store=F
         raise ValueError("weight shapes do not match C = {}".format(C))
     flags = int(bool(mish_on_load)) | (2 if mish_on_store else 0)
     if keep[0].dtype == torch.float16:
-        return _sepconv3x3_f16(keep, w, pw_padded, bias, flags, B, H, W, C, F_)
+        return _sepconv3x3_f16(keep, c_ptrs, c_ch, c_st, w, pw_padded, bias, flags, B, H, W, C, F_)
     if keep[0].dtype != torch.float32:
         raise ValueError("sepconv3x3 takes fp32 or fp16 sources")
     for t in (w, pw_padded, bias):
@@ -468,17 +468,18 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False, mish_on_store=F
     return out
 
 
-def _sepconv3x3_f16(keep, w, pw_padded, bias, flags, B, H, W, C, F_):
-    """fp16-storage form: one dense source, C % 8 == 0, pw_padded fp16 (qpwc_sepconv3x3_f16_fwd)."""
-    if len(keep) != 1 or C % 8 or keep[0].stride(2) % 8:
-        raise ValueError("fp16 sepconv3x3 takes one source of a multiple of 8 channels")
+def _sepconv3x3_f16(keep, c_ptrs, c_ch, c_st, w, pw_padded, bias, flags, B, H, W, C, F_):
+    """fp16-storage form (qpwc_sepconv3x3_f16_fwd): pw_padded fp16, dw / bias fp32."""
+    for i, t in enumerate(keep):
+        tail = i + 1 == len(keep) and t.shape[3] < 4
+        if not tail and (t.shape[3] % 4 or t.stride(2) % 4 or t.data_ptr() % 8):
+            raise ValueError("fp16 sepconv3x3: sources must hold multiples of 4 channels in 8-byte aligned pixels")
     for t, dt in ((w, torch.float32), (pw_padded, torch.float16), (bias, torch.float32)):
         if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
             raise ValueError("fp16 sepconv3x3: dw/bias dense fp32, pw dense fp16 device tensors")
-    x = keep[0]
-    out = torch.empty((B, H, W, F_), dtype=torch.float16, device=x.device)
+    out = torch.empty((B, H, W, F_), dtype=torch.float16, device=keep[0].device)
     with torch.cuda.device(out.device), _timed("sepconv3x3_f16", (B, H, W, C, F_)):
-        rc = _hip.lib().qpwc_sepconv3x3_f16_fwd(x.data_ptr(), C, x.stride(2), flags, w.data_ptr(),
+        rc = _hip.lib().qpwc_sepconv3x3_f16_fwd(c_ptrs, c_ch, c_st, len(keep), flags, w.data_ptr(),
                                                  pw_padded.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                                  B, H, W, F_, _stream(out))
     _hip.check(rc)

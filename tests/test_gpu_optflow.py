@@ -183,39 +183,47 @@ def test_sepconv3x3_fused(chans, F, hw, act):
     torch.testing.assert_close(out_act, torch_ref.mish(ref), rtol=0, atol=5e-5)
 
 
-@pytest.mark.parametrize("C,F", [(128, 64), (64, 32), (32, 16), (40, 128), (8, 16)])
+@pytest.mark.parametrize("chans,F", [((128,), 64), ((64,), 32), ((32,), 16), ((40,), 128), ((8,), 16), ((12,), 16),
+                                     ((84, 32, 2), 128), ((84, 256, 256), 128), ((84, 64, 2), 64)])
 @pytest.mark.parametrize("hw", [(8, 16), (19, 37)])
 @pytest.mark.parametrize("act", [False, True])
-def test_sepconv3x3_fused_fp16_storage(C, F, hw, act):
+def test_sepconv3x3_fused_fp16_storage(chans, F, hw, act):
     """qpwc_sepconv3x3_f16_fwd: fp16 in/out, fp32 depthwise rounded to fp16 once, f16 matrix cores with
-    fp32 accumulation.  Bound: the same rounding points restated on the oracle's ops (input and pointwise
-    weights fp16, depthwise result fp16) -> differences are accumulation order + the output rounding."""
+    fp32 accumulation; one dense source (16-byte loads) or the virtual concat of up to three (8-byte loads,
+    short last source element-wise).  Bound: the same rounding points restated on the oracle's ops (input
+    and pointwise weights fp16, depthwise result fp16) -> differences are accumulation order + the output
+    rounding."""
+    C = sum(chans)
     rng = np.random.default_rng(C + F + hw[0])
     H, W = hw
-    x = _rand(rng, 2, H, W, C).half()
+    srcs = [_rand(rng, 2, H, W, c).half() for c in chans]
     dw = _rand(rng, C, 1, 3, 3)
     pw = (_rand(rng, F, C, 1, 1) / np.sqrt(C)).half()
     bias = _rand(rng, F)
-    y = torch_ref.depthwise3x3([x.float()], dw, act).half().float()
+    y = torch_ref.depthwise3x3([x.float() for x in srcs], dw, act).half().float()
     ref = torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw.float(), bias).permute(0, 2, 3, 1)
     pw_pad = ops.pad_pointwise(pw.to(DEV), torch.float16)
-    out = ops.sepconv3x3([x.to(DEV)], dw.to(DEV), pw_pad, bias.to(DEV), mish_on_load=act)
+    dsrcs = [x.to(DEV) for x in srcs]
+    out = ops.sepconv3x3(dsrcs, dw.to(DEV), pw_pad, bias.to(DEV), mish_on_load=act)
     assert out.dtype == torch.float16 and out.shape == ref.shape
     # depthwise sums that land on an fp16 rounding boundary may round the other way (fma order)
     torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=4e-3)
-    out_act = ops.sepconv3x3([x.to(DEV)], dw.to(DEV), pw_pad, bias.to(DEV), mish_on_load=act,
-                             mish_on_store=True)
+    out_act = ops.sepconv3x3(dsrcs, dw.to(DEV), pw_pad, bias.to(DEV), mish_on_load=act, mish_on_store=True)
     torch.testing.assert_close(out_act.float().cpu(), torch_ref.mish(ref), rtol=2e-3, atol=4e-3)
 
 
 def test_sepconv3x3_fp16_rejects_unaligned_sources():
-    x = torch.zeros((1, 8, 16, 12), dtype=torch.float16, device=DEV)
-    dw = torch.zeros((12, 9), device=DEV)
+    x = torch.zeros((1, 8, 16, 6), dtype=torch.float16, device=DEV)
+    dw = torch.zeros((6, 9), device=DEV)
     pw = torch.zeros((16, 32), dtype=torch.float16, device=DEV)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):   # 6 channels: neither a multiple of 4 nor a short tail
         ops.sepconv3x3([x], dw, pw, torch.zeros(16, device=DEV))
+    with pytest.raises(ValueError):   # an odd-width source in front of another one (the dense 81-channel volume)
+        ops.sepconv3x3([torch.zeros((1, 8, 16, 81), dtype=torch.float16, device=DEV), x[..., :4].contiguous()],
+                       torch.zeros((85, 9), device=DEV), torch.zeros((16, 96), dtype=torch.float16, device=DEV),
+                       torch.zeros(16, device=DEV))
     with pytest.raises(ValueError):   # fp32 pointwise weights with fp16 sources
-        ops.sepconv3x3([x[..., :8].contiguous()], dw[:8], pw.float(), torch.zeros(16, device=DEV))
+        ops.sepconv3x3([x[..., :4].contiguous()], dw[:4], pw.float(), torch.zeros(16, device=DEV))
 
 
 def test_optflow_fp16_fused_and_unfused_sepconv_agree():
@@ -229,6 +237,9 @@ def test_optflow_fp16_fused_and_unfused_sepconv_agree():
     try:
         non_layers.OptFlow.fused_sepconv = True
         a = of.from_sources(srcs).float().cpu()
+        # the zero-padded 84-channel cost volume lets the first layer fuse as well
+        cost84 = torch.cat([srcs[0], torch.zeros_like(srcs[0][..., :3])], dim=3)
+        c = of.from_sources([cost84] + srcs[1:]).float().cpu()
         non_layers.OptFlow.fused_sepconv = False
         b = of.from_sources(srcs).float().cpu()
     finally:
@@ -236,6 +247,7 @@ def test_optflow_fp16_fused_and_unfused_sepconv_agree():
     scale = float(hw[0] ** 2 + hw[1] ** 2) ** 0.5
     assert a.abs().max() > 0
     torch.testing.assert_close(a / scale, b / scale, rtol=0, atol=3e-3)
+    torch.testing.assert_close(c / scale, b / scale, rtol=0, atol=3e-3)
 
 
 def test_optflow_fused_and_unfused_sepconv_agree():
