@@ -233,17 +233,17 @@ def main():
             def run():
                 for _ in range(n_rep):
                     fn()
+        run()   # one untimed replay: clocks and caches in their steady state
         torch.cuda.synchronize()
-        best = None
-        for _ in range(3):
+        ts = []
+        for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run()
             e1.record()
             e1.synchronize()
-            t = e0.elapsed_time(e1) / n_rep
-            best = t if best is None else min(best, t)
-        return best
+            ts.append(e0.elapsed_time(e1) / n_rep)
+        return sorted(ts)[len(ts) // 2]   # median round, not the best one
 
     if kt.captured is not None:
         # The eager pass times event -> (host launch latency) -> kernel -> event.  For the launch
@@ -253,14 +253,27 @@ def main():
         cbuf = torch.empty(cp.shape[:3] + (cstride,), dtype=cp.dtype, device=cp.device)
         dom_ms = replay_launches(lambda: ops.cost_volume_into(cp, cn, cbuf, 0))
     dom_bytes = cost_volume_bytes(*lvl4, esize)
-    # The same kernel symbol also serves level 3 (one launch per step each): time that launch the
-    # same way so that the mean is comparable with rocprofv3's per-symbol AverageNs.
-    sym_avg_ms = None
+    # The same kernel symbol also serves the coarser levels that give it >= 256 regions of 8x8 pixels (L2
+    # and L3 at B=8, 256x512; one launch per step each): time those launches the same way, so that the
+    # per-level figures compare with rocprofv3's per-grid durations and their mean with its per-symbol
+    # AverageNs.
+    sym_avg_ms, sym_by_level = None, None
     if kt.captured is not None and not args.fused:
-        p3 = torch.randn(lvl3, device=dev, dtype=tdtype)
-        n3 = torch.randn(lvl3, device=dev, dtype=tdtype)
-        b3 = torch.empty(lvl3[:3] + (kt.captured[2],), dtype=tdtype, device=dev)
-        sym_avg_ms = 0.5 * (dom_ms + replay_launches(lambda: ops.cost_volume_into(p3, n3, b3, 0)))
+        sym_by_level = {"L4": dom_ms}
+        chans = synth.level_channels()
+        for lv in (3, 2, 1, 0):
+            shp = (B, hw[0] >> (5 - lv), hw[1] >> (5 - lv), chans[lv])
+            regions = B * ((shp[1] + 7) // 8) * ((shp[2] + 7) // 8)
+            if shp[3] % 32 or regions < 256:
+                break
+            pl = torch.randn(shp, device=dev, dtype=tdtype)
+            nl = torch.randn(shp, device=dev, dtype=tdtype)
+            # the step writes 84-channel pixels where the first OptFlow layer is fused, dense 81 elsewhere
+            blk = model.flow if lv == 0 else model.upflows[lv - 1]
+            stride = kt.captured[2] if blk.flow.wants_cost84(pl) else 81
+            bl = torch.empty(shp[:3] + (stride,), dtype=tdtype, device=dev)
+            sym_by_level["L%d" % lv] = replay_launches(lambda: ops.cost_volume_into(pl, nl, bl, 0))
+        sym_avg_ms = sum(sym_by_level.values()) / len(sym_by_level)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from a separate rocprofv3 --pmc run
@@ -298,7 +311,8 @@ def main():
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
             "avg_launch_ms_inside_eager_step": dom_ms_eager,
             "kernel_symbol": "cost_volume_mfma_lds_kernel" if args.dtype == "f32" else "cost_volume_mfma_lds_f16_kernel",
-            "symbol_avg_ms_L3_and_L4": sym_avg_ms,  # compare with rocprofv3 --stats AverageNs of the symbol
+            # compare with rocprofv3: per-grid durations of the symbol / its --stats AverageNs
+            "symbol_launch_ms_by_level": sym_by_level, "symbol_avg_ms": sym_avg_ms,
             "launches_timed": ktimes[dom_key][0],
             "out_pixel_stride": kt.captured[2] if kt.captured is not None else None,
             "method": "HIP events on the launch stream around a hipGraph of 50 back-to-back replays of the "
