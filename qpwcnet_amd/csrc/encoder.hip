@@ -12,7 +12,12 @@
 // Workgroup = 4 waves = an 8 x 16 pixel tile; a wave owns two tile rows.  k-slot g of a lane owns
 // channels 4g..4g+3 of a 16-channel chunk, so every operand is one 16-byte access; LDS pixels are
 // C floats with the 16-byte chunk c of halo pixel p stored at chunk c ^ ((p >> 1) & (C/4 - 1)) for
-// C = 32 (C = 16: a wave reads 1 KB contiguous, no swizzle needed).
+// C = 32, c ^ ((p >> 2) & 3) for C = 16 (ec_slot).
+// Measured, 16 x 128 x 256 x 16 (36 us): without the matrix instructions 23 us, without Mish 31.5, without
+// the halo loads 33.5 -- one tile per workgroup runs the chip in rounds (all resident workgroups load,
+// then all compute).  Resident workgroups walking the tiles with the next halo prefetched into registers
+// and a double-buffered LDS image need 144 / 196 registers (loop-invariant addresses stay live): 34.7 us
+// at C = 16, 34.8 (from 31.8) at C = 32 -- not kept.
 #include "common.h"
 
 namespace qpwc {
@@ -31,6 +36,15 @@ constexpr int kEcTH = 8, kEcTW = 16;
 constexpr int kEcHW = kEcTW + 2, kEcNH = (kEcTH + 2) * kEcHW;   // 180 halo pixels
 
 // weight: [9 taps][C out][C in] fp32; out: (B, H + pad_h, W + pad_w, C), border zero
+// 16-byte chunk q of halo pixel hp sits at chunk ec_slot(q, hp) of the pixel's row: the matrix operand
+// reads (16 lanes = 16 consecutive pixels, one chunk each) must cover all 64 banks.  128-B pixels
+// (C = 32): q ^ (hp >> 1); 64-B pixels (C = 16): four pixels span the banks once, so the pixels
+// hp, hp+4, hp+8, hp+12 of a read need four different chunks: q ^ (hp >> 2).
+template <int C>
+__device__ __forceinline__ int ec_slot(int q, int hp) {
+    return C == 16 ? (q ^ ((hp >> 2) & 3)) : (q ^ ((hp >> 1) & (C / 4 - 1)));
+}
+
 template <int C>
 __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ weight,
@@ -56,7 +70,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
         const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)gy * W + gx) * C + 4 * q);
-        const int slot = C == 16 ? q : (q ^ ((hp >> 1) & (NQ - 1)));
+        const int slot = ec_slot<C>(q, hp);
         *reinterpret_cast<float4*>(in_s + hp * C + 4 * slot) = v;
     }
     __syncthreads();
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
                     for (int m = 0; m < 2; ++m) {
                         const int hp = (2 * wave + m + ky) * kEcHW + n + kx;
                         const int q = 4 * kc + g;
-                        const int slot = C == 16 ? q : (q ^ ((hp >> 1) & (NQ - 1)));
+                        const int slot = ec_slot<C>(q, hp);
                         bv[m] = *reinterpret_cast<const f32x4e*>(in_s + hp * C + 4 * slot);
                     }
                     // alternate the two accumulators: a dependent matrix instruction issued back to back
@@ -233,7 +247,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3s2_mish_kernel(const float* __r
         const int gy = 2 * Y0 + row, gx = 2 * X0 + col;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gy < Hp && gx < Wp) v = *reinterpret_cast<const float4*>(xb + ((int64_t)gy * Wp + gx) * CI + 4 * q);
-        *reinterpret_cast<float4*>(in_s + (((col & 1) * kS2IH + row) * kS2PW + (col >> 1)) * CI + 4 * q) = v;
+        const int pix = ((col & 1) * kS2IH + row) * kS2PW + (col >> 1);
+        *reinterpret_cast<float4*>(in_s + pix * CI + 4 * ec_slot<CI>(q, pix)) = v;
     }
     f32x4e wv[9][2];
 #pragma unroll
@@ -257,7 +272,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3s2_mish_kernel(const float* __r
             for (int m = 0; m < 2; ++m) {
                 const int row = 2 * (2 * wave + m) + ky;            // input row of output row 2 wave + m
                 const int par = kx & 1, pc = n + (kx >> 1);          // column 2 n + kx -> plane, index
-                bv[m] = *reinterpret_cast<const f32x4e*>(in_s + ((par * kS2IH + row) * kS2PW + pc) * CI + 4 * g);
+                const int pix = (par * kS2IH + row) * kS2PW + pc;
+                bv[m] = *reinterpret_cast<const f32x4e*>(in_s + pix * CI + 4 * ec_slot<CI>(g, pix));
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
