@@ -127,6 +127,15 @@ int qpwc_epe_multi_workspace_floats(void);
 int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
                        int n_levels, void* out_means, void* workspace, void* stream);
 
+/* cost_volume_to_flow (qpwcnet/core/vis.py:9-34): flow[b,y,x] = (di, dj), the (row, column) displacement
+ * of the first maximum over the D = d*d channels of a cost volume: imax = argmax_k, q = sqrt(D),
+ * di = floor(imax/q) - (q-1)/2, dj = imax - floor(imax/q)*q - (q-1)/2 in fp32 like the reference.
+ * cvol: (B,H,W,D) read at pixel_stride elements per pixel (>= D: the 84-channel padded volume decodes
+ * in place) or (B,D,H,W) (pixel_stride == D); fp32 or fp16.  flow: fp32 (B,H,W,2) / (B,2,H,W).
+ * NaN-free input assumed (tf.argmax's NaN ordering is not reproduced). */
+int qpwc_cost_volume_to_flow_fwd(const void* cvol, void* flow, int B, int H, int W, int D,
+                                 int64_t pixel_stride, int layout, int dtype, void* stream);
+
 /* ---- OptFlow block, the step right after the cost volume at every level
  * (reference qpwcnet/core/non_layers.py:213-273) ---------- */
 

@@ -41,6 +41,8 @@ int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* 
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
                      int act, const void* weight, void* out, int B, int H, int W, int dtype,
                      hipStream_t s);
+int cost_volume_to_flow_launch(const void* cvol, float* flow, int B, int H, int W, int D, int64_t pix_stride,
+                               int layout, int dtype, hipStream_t s);
 int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src, int act,
                           const void* dw, const void* pw, const void* bias, void* out, int B, int H, int W,
                           int F, hipStream_t s);
@@ -378,6 +380,21 @@ int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, con
     }
     return epe_multi_launch(y_true, y_pred, n_pixels, n_levels, (float*)out_means, (float*)workspace,
                             (hipStream_t)stream);
+}
+
+int qpwc_cost_volume_to_flow_fwd(const void* cvol, void* flow, int B, int H, int W, int D,
+                                 int64_t pixel_stride, int layout, int dtype, void* stream) {
+    if (!cvol || !flow) return fail(QPWC_E_NULL, "null pointer argument");
+    const int rc = check_common(B, H, W, D, layout, dtype);
+    if (rc) return rc;
+    if (layout == QPWC_NHWC ? pixel_stride < D : pixel_stride != D)
+        return fail(QPWC_E_STRIDE, "pixel stride %lld for %d channels", (long long)pixel_stride, D);
+    if ((uintptr_t)cvol % esize(dtype) || (uintptr_t)flow % 8)
+        return fail(QPWC_E_ALIGN, "cvol must be element aligned, flow 8-byte aligned");
+    if (overlaps(flow, (size_t)B * H * W * 8, cvol, (size_t)B * H * W * pixel_stride * esize(dtype)))
+        return fail(QPWC_E_ALIAS, "flow overlaps cvol");
+    return cost_volume_to_flow_launch(cvol, (float*)flow, B, H, W, D, pixel_stride, layout, dtype,
+                                      (hipStream_t)stream);
 }
 
 static int check_flow_args(const void* flow, const void* out, int B, int H, int W, int layout, int dtype,

@@ -173,4 +173,82 @@ int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int
     return check_launch("epe_final_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// cost_volume_to_flow (qpwcnet/core/vis.py:9-34): per pixel the displacement of the strongest
+// correlation, imax = argmax_k cvol[..., k] (first maximum, as tf.argmax), q = sqrt(D),
+// di = floor(imax / q) - (q-1)/2, dj = imax - floor(imax / q) * q - (q-1)/2, all in fp32 as the
+// reference computes them; out = (di, dj) = (row, column) displacement -- the decode that pins the
+// channel order i0 * 9 + j0 of the cost volume.
+// NHWC: 16 lanes per pixel scan channels l, l+16, ... (64-byte coalesced runs) and reduce with
+// shuffles; NCHW: one thread per pixel walks the D planes (coalesced across pixels).
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void cost_volume_to_flow_kernel(const T* __restrict__ cvol,
+                                                                  float* __restrict__ flow, int64_t npix,
+                                                                  int64_t plane, int D, int64_t pix_stride,
+                                                                  float q) {
+    if (LAYOUT == QPWC_NHWC) {
+        const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+        const int l = threadIdx.x & 15;
+        float best = -INFINITY;
+        int arg = 0x7fffffff;
+        if (p < npix) {
+            const T* src = cvol + p * pix_stride;
+            for (int k = l; k < D; k += 16) {
+                const float v = ld<T>(src + k);
+                if (v > best || arg == 0x7fffffff) { best = v; arg = k; }   // strictly greater: first maximum wins
+            }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 16);
+            const int oa = __shfl_xor(arg, off, 16);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        if (p < npix && l == 0) {
+            const float im = (float)arg;
+            const float fi = floorf(im / q);
+            const float dj = im - fi * q;
+            const float half = (q - 1.0f) / 2.0f;
+            *reinterpret_cast<float2*>(flow + 2 * p) = make_float2(fi - half, dj - half);
+        }
+    } else {
+        const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (p >= npix) return;
+        const int64_t b = p / plane, r = p - b * plane;
+        const T* src = cvol + b * D * plane + r;
+        float best = ld<T>(src);
+        int arg = 0;
+        for (int k = 1; k < D; ++k) {
+            const float v = ld<T>(src + (int64_t)k * plane);
+            if (v > best) { best = v; arg = k; }
+        }
+        const float im = (float)arg;
+        const float fi = floorf(im / q);
+        const float dj = im - fi * q;
+        const float half = (q - 1.0f) / 2.0f;
+        flow[(b * 2) * plane + r] = fi - half;
+        flow[(b * 2 + 1) * plane + r] = dj - half;
+    }
+}
+
+int cost_volume_to_flow_launch(const void* cvol, float* flow, int B, int H, int W, int D, int64_t pix_stride,
+                               int layout, int dtype, hipStream_t s) {
+    const int64_t npix = (int64_t)B * H * W, plane = (int64_t)H * W;
+    const float q = sqrtf((float)D);
+    const int64_t threads = layout == QPWC_NHWC ? npix * 16 : npix;
+    const int64_t nblk = (threads + 255) / 256;
+    if (nblk > INT32_MAX) {
+        set_error("cost_volume_to_flow: too many pixels");
+        return QPWC_E_SHAPE;
+    }
+    const dim3 grid((unsigned)nblk);
+#define QPWC_CVF(T, L)                                                                                      \
+    hipLaunchKernelGGL((cost_volume_to_flow_kernel<T, L>), grid, dim3(256), 0, s, (const T*)cvol, flow, npix, \
+                       plane, D, pix_stride, q)
+    if (dtype == QPWC_F32) { if (layout == QPWC_NHWC) QPWC_CVF(float, QPWC_NHWC); else QPWC_CVF(float, QPWC_NCHW); }
+    else                   { if (layout == QPWC_NHWC) QPWC_CVF(__half, QPWC_NHWC); else QPWC_CVF(__half, QPWC_NCHW); }
+#undef QPWC_CVF
+    return check_launch("cost_volume_to_flow_kernel");
+}
+
 }  // namespace qpwc

@@ -142,6 +142,37 @@ def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST, lrelu_slope
     return out
 
 
+def cost_volume_to_flow(cvol, data_format=CHANNELS_LAST):
+    """Displacement of the strongest correlation per pixel, (di, dj) = (row, column)
+    (qpwcnet/core/vis.py:9-34): fp32 (..., H, W, 2) / (..., 2, H, W).  Rank 4 or unbatched rank 3 (the
+    reference's channels_first branch only parses rank 3, vis.py:19-20; both ranks work here for both
+    layouts).  A channels-last view with a wider pixel stride (the 84-channel padded volume's [..., :81])
+    is read in place."""
+    if not isinstance(cvol, torch.Tensor) or cvol.dim() not in (3, 4):
+        raise ValueError("cvol must be a rank 3 or 4 tensor, got {}".format(
+            tuple(cvol.shape) if isinstance(cvol, torch.Tensor) else type(cvol)))
+    x = cvol if cvol.dim() == 4 else cvol.unsqueeze(0)
+    _check_tensor("cvol", x)
+    if data_format == CHANNELS_LAST:
+        B, H, W, D = x.shape
+        if x.stride(3) != 1 or x.stride(1) != W * x.stride(2) or x.stride(0) != H * x.stride(1) or x.stride(2) < D:
+            x = x.contiguous()
+        layout, stride = _hip.NHWC, x.stride(2)
+        out = torch.empty((B, H, W, 2), dtype=torch.float32, device=x.device)
+    elif data_format == CHANNELS_FIRST:
+        B, D, H, W = x.shape
+        x = x.contiguous()
+        layout, stride = _hip.NCHW, D
+        out = torch.empty((B, 2, H, W), dtype=torch.float32, device=x.device)
+    else:
+        raise ValueError("Unsupported data format : {}".format(data_format))
+    with torch.cuda.device(x.device), _timed("cost_volume_to_flow", (B, H, W, D)):
+        rc = _hip.lib().qpwc_cost_volume_to_flow_fwd(x.data_ptr(), out.data_ptr(), B, H, W, D, stride, layout,
+                                                      _DTYPES[x.dtype], _stream(x))
+    _hip.check(rc)
+    return out if cvol.dim() == 4 else out[0]
+
+
 def _flow_physical(flo, dims, data_format, layout):
     """fp32 flow, dense over its non-broadcast dims, in the layout the image uses."""
     B, H, W, _ = dims

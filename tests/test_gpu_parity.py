@@ -448,3 +448,40 @@ def test_cost_volume_84_channel_padded_layout(shape):
     bh = torch.full(shape[:3] + (84,), float("nan"), device=DEV, dtype=torch.float16)
     ops.cost_volume_into(prv.half(), nxt.half(), bh, 0)
     assert torch.equal(bh[..., :81], h) and float(bh[..., 81:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 24, 28, 81), torch.float32), ((1, 7, 5, 81), torch.float16),
+                                         ((3, 9, 11, 25), torch.float32), ((8, 128, 256, 81), torch.float32)])
+def test_cost_volume_to_flow_decode(shape, dtype):
+    """cost_volume_to_flow (qpwcnet/core/vis.py:9-34) on the device: bit-exact against the numpy
+    restatement, both layouts, ties resolved to the first maximum like tf.argmax, unbatched input, and the
+    84-channel padded volume decoded in place."""
+    from qpwcnet_amd import vis
+    g = torch.Generator(device="cpu").manual_seed(shape[1])
+    cv = torch.randn(*shape, generator=g).to(dtype)
+    cv[0, 1, 1, :] = 0.25            # a pixel whose channels all tie: argmax = 0
+    cv[0, 2, 3, 7] = cv[0, 2, 3, shape[3] - 3] = 9.0   # two equal maxima: the first one
+    ref = np_ref.cost_volume_to_flow(cv.float().numpy())
+    out = vis.cost_volume_to_flow(cv.to(DEV), "channels_last")
+    assert out.dtype == torch.float32
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    out_cf = ops.cost_volume_to_flow(cv.permute(0, 3, 1, 2).contiguous().to(DEV), "channels_first")
+    np.testing.assert_array_equal(out_cf.permute(0, 2, 3, 1).cpu().numpy(), ref)
+    np.testing.assert_array_equal(ops.cost_volume_to_flow(cv[0].to(DEV)).cpu().numpy(), ref[0])
+    if shape[3] == 81:
+        wide = torch.full(shape[:3] + (84,), 100.0, dtype=dtype)     # pads must not be read
+        wide[..., :81] = cv
+        np.testing.assert_array_equal(ops.cost_volume_to_flow(wide.to(DEV)[..., :81]).cpu().numpy(), ref)
+
+
+def test_cost_volume_to_flow_recovers_a_shift_on_the_device():
+    """nxt = prv moved by (dy, dx): the decoded flow of the HIP cost volume is (dy, dx) in the interior."""
+    rng = np.random.default_rng(5)
+    prv = rng.standard_normal((2, 24, 32, 32)).astype(np.float32)
+    for dy, dx in ((0, 0), (2, -3), (-4, 4)):
+        nxt = np.roll(prv, (dy, dx), axis=(1, 2))
+        cv = ops.cost_volume(torch.from_numpy(prv).to(DEV), torch.from_numpy(nxt).to(DEV))
+        flow = ops.cost_volume_to_flow(cv).cpu().numpy()[:, 8:16, 8:24]
+        assert np.all(flow[..., 0] == dy) and np.all(flow[..., 1] == dx)
+    with pytest.raises(ValueError):
+        ops.cost_volume_to_flow(torch.zeros(4, 4, device=DEV))
