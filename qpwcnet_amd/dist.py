@@ -64,6 +64,57 @@ def gather_epe(local_epe, n_local=None):
     return per_rank, (per_rank * weights).sum(dim=0) / weights.sum()
 
 
+class EpeGather:
+    """The same exchange with the collective of step k in flight behind the compute of step k+1:
+    ``submit(local_epe)`` copies the vector into one of two payload buffers and starts an asynchronous
+    all-gather (on RCCL's own stream, ordered after the caller's stream up to this point);
+    ``collect()`` returns the OLDEST outstanding result -- the caller's stream waits for that collective,
+    which by then has had a whole step to finish -- as (per_rank [world, L], global_mean [L]).
+    Buffers are allocated once; nothing is copied from the host per step.  Single process: no
+    collective, submit/collect are a queue of clones."""
+
+    def __init__(self, n_levels, device, n_local=1, dtype=torch.float32):
+        # a process group of one rank still runs the collective (that is how the RCCL path is tested on
+        # a one-GPU box); no process group = plain single process
+        self.collective = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.collective else 1
+        self.L = int(n_levels)
+        self.pending = []
+        self.slot = 0
+        if self.collective:
+            w = self.L + 1
+            self.payload = [torch.zeros(w, dtype=dtype, device=device) for _ in range(2)]
+            for p in self.payload:
+                p[-1] = float(n_local)      # shard weight, constant over the run
+            self.flat = [torch.empty(self.world * w, dtype=dtype, device=device) for _ in range(2)]
+
+    def submit(self, local_epe):
+        if not self.collective:
+            self.pending.append((None, local_epe.clone()))
+            return
+        if len(self.pending) >= 2:
+            raise RuntimeError("EpeGather: collect() the oldest result before submitting a third")
+        k = self.slot
+        self.slot ^= 1
+        self.payload[k][:self.L].copy_(local_epe)
+        work = dist.all_gather_into_tensor(self.flat[k], self.payload[k], async_op=True)
+        self.pending.append((work, self.flat[k]))
+
+    def collect(self):
+        if not self.pending:
+            raise RuntimeError("EpeGather: nothing submitted")
+        work, buf = self.pending.pop(0)
+        if not self.collective:
+            return buf.unsqueeze(0), buf
+        work.wait()
+        out = buf.view(self.world, self.L + 1)
+        per_rank, weights = out[:, :-1], out[:, -1:]
+        return per_rank.clone(), (per_rank * weights).sum(dim=0) / weights.sum()
+
+    def outstanding(self):
+        return len(self.pending)
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -32,6 +32,18 @@ def test_single_process_gather_is_identity():
     assert qdist.max_over_ranks(1.5, "cpu") == 1.5
 
 
+def test_single_process_pipelined_gather():
+    eg = qdist.EpeGather(6, "cpu")
+    v = torch.arange(6, dtype=torch.float32)
+    eg.submit(v)
+    eg.submit(v + 1)
+    pr, mean = eg.collect()
+    assert pr.shape == (1, 6) and torch.equal(mean, v)
+    assert torch.equal(eg.collect()[1], v + 1) and eg.outstanding() == 0
+    with pytest.raises(RuntimeError):
+        eg.collect()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -56,6 +68,17 @@ def _worker(rank, world, port, q):
                          dtype=torch.float32)
     per_rank, mean = qd.gather_epe(local, hi - lo)
     full = [np_ref.epe_error(true * s, pred * s) for s in (1, 2, 3)]
+    # the pipelined form bench.py uses: two collectives in flight, results come back in order
+    eg = qd.EpeGather(3, "cpu", n_local=hi - lo)
+    eg.submit(local)
+    eg.submit(local * 2)
+    pr_a, mean_a = eg.collect()
+    eg.submit(local * 3)
+    pr_b, mean_b = eg.collect()
+    pr_c, mean_c = eg.collect()
+    assert eg.outstanding() == 0
+    assert torch.equal(pr_a, per_rank) and torch.allclose(mean_a, mean)
+    assert torch.allclose(mean_b, 2 * mean) and torch.allclose(mean_c, 3 * mean) and torch.equal(pr_c, 3 * per_rank)
     t = qd.max_over_ranks(float(rank + 1), "cpu")
     qd.barrier()
     q.put((rank, per_rank.numpy(), mean.numpy(), np.asarray(full, np.float32), t))
