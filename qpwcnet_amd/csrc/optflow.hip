@@ -964,33 +964,44 @@ __global__ __launch_bounds__(256, 2) void flow_head_kernel(const T* __restrict__
     const float4 b1v = *reinterpret_cast<const float4*>(b1 + 4 * g);
     const float4 bsv = *reinterpret_cast<const float4*>(bs + 4 * g);
     const float4 btv = *reinterpret_cast<const float4*>(bt + 4 * g);
-    for (int grp = wave; grp < (NH + 15) / 16; grp += 4) {
-        const int hp = 16 * grp + n;
+    // the 72 weights of this lane's 4 input channels, wf[ky][kx][in][out] (in flight with the halo loads)
+    float4 wq[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        wq[k][0] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g);       // (c0:x,y) (c1:x,y)
+        wq[k][1] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g + 4);   // (c2:x,y) (c3:x,y)
+    }
+    // a wave takes halo groups wave, wave+4, ... (at most 6); all of its loads are issued before the first
+    // use (one exposed memory latency per workgroup instead of one per group)
+    constexpr int NG = (NH + 15) / 16, NGW = (NG + 3) / 4;
+    float4 av[NGW];
+    bool inb[NGW];
+#pragma unroll
+    for (int i = 0; i < NGW; ++i) {
+        const int hp = 16 * (wave + 4 * i) + n;
         const int ly = hp / TW, lx = hp - ly * TW;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-        const bool in = hp < NH && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) {
-            a = ld4(zb + ((int64_t)gy * W + gx) * kFhC + 4 * g);
-            a = make_float4(mishf(a.x), mishf(a.y), mishf(a.z), mishf(a.w));
-        }
+        inb[i] = hp < NH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inb[i]) av[i] = ld4(zb + ((int64_t)gy * W + gx) * kFhC + 4 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < NGW; ++i) {
+        const int grp = wave + 4 * i;
+        if (grp >= NG) break;   // wave-uniform
+        const int hp = 16 * grp + n;
+        float4 a = av[i];
+        if (inb[i]) a = make_float4(mishf(a.x), mishf(a.y), mishf(a.z), mishf(a.w));
         f32x4v d = {0.f, 0.f, 0.f, 0.f};
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[0], a.x, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[1], a.y, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[2], a.z, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[3], a.w, d, 0, 0, 0);
         float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in)
+        if (inb[i])
             h = make_float4(fmaf(mishf(d[0] + b1v.x), bsv.x, btv.x), fmaf(mishf(d[1] + b1v.y), bsv.y, btv.y),
                             fmaf(mishf(d[2] + b1v.z), bsv.z, btv.z), fmaf(mishf(d[3] + b1v.w), bsv.w, btv.w));
         *reinterpret_cast<float4*>(hs + hp * kFhC + 4 * g) = h;
-    }
-    // the 72 weights of this lane's 4 input channels: wf[ky][kx][in][out]
-    float4 wq[9][2];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        wq[k][0] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g);       // (c0:x,y) (c1:x,y)
-        wq[k][1] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g + 4);   // (c2:x,y) (c3:x,y)
     }
     __syncthreads();
 
