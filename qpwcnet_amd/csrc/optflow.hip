@@ -593,9 +593,11 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// fp16-storage form of the fused SeparableConv2D (BASELINE configs[4]): one dense source whose
-// pixels are 16-byte aligned runs of a multiple of 8 channels (OptFlow's layers 2..4), fp16 in and
-// out, the depthwise 3x3 in fp32 on the staged (and, on request, Mish-activated) tile, its result
+// fp16-storage form of the fused SeparableConv2D (BASELINE configs[4]): either one dense source whose
+// pixels are 16-byte aligned runs of a multiple of 8 channels (OptFlow's layers 2..4, WIDE) or the
+// virtual concat of up to three sources in 8-byte aligned runs of 4 channels (the first layer's
+// [cost 81 + 3 zero pads | prv | flo]; a last source of fewer than 4 channels is read element-wise); fp16
+// in and out, the depthwise 3x3 in fp32 on the staged (and, on request, Mish-activated) tile, its result
 // rounded to fp16 -- the same rounding point as the depthwise kernel + fp16 GEMM it replaces -- and
 // the pointwise conv as ONE v_mfma_f32_16x16x32_f16 (fp32 accumulate) per accumulator and step.
 // y_s / w_s rows are 64 B (32 halves) with the 16-byte chunk c of row n at chunk c ^ ((n >> 2) & 2),
