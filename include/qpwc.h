@@ -227,7 +227,7 @@ int qpwc_occlusion_fwd(const void* flow, void* out, int B, int H, int W, int lay
 
 /* One 3x3 stride-1 Conv2D(padding='same', activation='Mish') of the encoder's DownConv blocks
  * (conv_aa / conv_b, non_layers.py:410-449 with use_normalizer=False, pwcnet.py:146) for C_in = C_out = C
- * in {16, 32}, channels-last fp32: out (B, H+pad_h, W+pad_w, C), interior = Mish(conv3x3(x) + bias),
+ * in {16, 32, 64, 128, 256}, channels-last fp32: out (B, H+pad_h, W+pad_w, C), interior = Mish(conv3x3(x) + bias),
  * border (the 'SAME' padding of a following stride-2 convolution, non_layers.py:402-409) = 0.
  * weight: (9, C, C) fp32 = [ky*3+kx][out][in]; x: (B,H,W,C); all pointers 16-byte aligned. */
 int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,

@@ -430,7 +430,8 @@ int qpwc_occlusion_fwd(const void* flow, void* out, int B, int H, int W, int lay
 int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,
                           int W, int C, int pad_h, int pad_w, void* stream) {
     if (!x || !weight || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
-    if (C != 16 && C != 32) return fail(QPWC_E_SHAPE, "C=%d not in {16,32}", C);
+    if (C != 16 && C != 32 && C != 64 && C != 128 && C != 256)
+        return fail(QPWC_E_SHAPE, "C=%d not in {16,32,64,128,256}", C);
     if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || pad_h > 8 || pad_w > 8)
         return fail(QPWC_E_SHAPE, "bad shape B=%d H=%d W=%d pad=%d,%d", B, H, W, pad_h, pad_w);
     if ((uintptr_t)x % 16 || (uintptr_t)weight % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)

@@ -142,6 +142,146 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------
+// The same layer at the wide encoder levels (C_in = C_out = 64 / 128 / 256; 32x64 .. 8x16 pixel images
+// at 256x512): the weights no longer fit a wave's registers for all outputs, so a wave owns ONE block
+// of 16 outputs for ALL pixels of the tile (TH x 16 pixels = TH accumulators) and keeps that block's
+// weights for 32 input channels at a time in registers (9 taps x 2 k-chunks x 4 = 72, the next 32
+// channels' block prefetched into a second set); a workgroup =
+// 4 waves = 64 outputs, the grid = tiles x C/64 output slices.  TH = 8 / 4 / 2 keeps the grid at one
+// workgroup per CU for the 256x512 pyramid (256 workgroups at every level) and the work per wave
+// constant (1152 matrix instructions).  Every B operand (16 pixels x 4 channels per k-slot) is one
+// ds_read_b128 from the halo tile and feeds 4 matrix instructions; LDS pixels are C floats with the
+// 16-byte chunk q of halo pixel p at q ^ (p & 15) (16 consecutive pixels of one chunk cover all banks).
+// Replaces library convolution (73 TF) + bias/Mish pass (+ a zeroing launch for its split-K variants).
+template <int C, int TH>
+__global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ weight,
+                                                                   const float* __restrict__ bias,
+                                                                   float* __restrict__ out, int H, int W,
+                                                                   int pad_h, int pad_w, int tiles_x,
+                                                                   int tiles_y, int n_tiles) {
+    constexpr int NQ = C / 4;                      // 16-byte chunks per pixel
+    constexpr int HH = TH + 2, NH = HH * kEcHW;    // halo rows / pixels
+    constexpr int NKB = C / 32;                    // 32-channel blocks of the reduction
+    constexpr int NST = (NH * NQ + 255) / 256;     // staging loads per thread
+    __shared__ __attribute__((aligned(16))) float in_s[NH * C];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int slice = blockIdx.x / n_tiles;                       // 64 outputs
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * TH;
+    const int fo = 64 * slice + 16 * wave;                        // this wave's output block
+    const float* xb = x + (int64_t)b * H * W * C;
+
+    // ---- stage the halo tile (zero outside the image): all loads first, then the LDS writes ----
+    {
+        float4 st[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            st[it] = (idx < NH * NQ && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                         ? *reinterpret_cast<const float4*>(xb + ((int64_t)gy * W + gx) * C + 4 * q)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            if (idx < NH * NQ) *reinterpret_cast<float4*>(in_s + hp * C + 4 * (q ^ (hp & 15))) = st[it];
+        }
+    }
+    f32x4e acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    // weights of output row fo + n, input channels 32 kb + 16 kc + 4 g .. + 3, 9 taps: 72 registers per
+    // block, the next block's loads are issued before the current block's matrix instructions
+    f32x4e wv[9][2], wn[9][2];
+    auto load_w = [&](f32x4e (&w)[9][2], int kb) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+                w[k][kc] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)k * C + fo + n) * C + 32 * kb + 16 * kc + 4 * g);
+    };
+    load_w(wv, 0);
+    __syncthreads();   // the halo tile is complete (the first weight loads are in flight behind it)
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    f32x4e bv[TH];
+#pragma unroll
+                    for (int m = 0; m < TH; ++m) {
+                        const int hp = (m + ky) * kEcHW + n + kx;
+                        const int q = 8 * kb + 4 * kc + g;
+                        bv[m] = *reinterpret_cast<const f32x4e*>(in_s + hp * C + 4 * (q ^ (hp & 15)));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int m = 0; m < TH; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[m][t], acc[m], 0, 0, 0);
+                }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) wv[k][kc] = wn[k][kc];
+    }
+    // ---- bias + Mish: lane = pixel n of tile row m, outputs fo + 4g .. + 3 ----
+    const int Ho = H + pad_h, Wo = W + pad_w;
+    float* ob = out + (int64_t)b * Ho * Wo * C;
+    const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+    for (int m = 0; m < TH; ++m) {
+        const int gy = Y0 + m, gx = X0 + n;
+        if (gy < H && gx < W)
+            *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * C + fo + 4 * g) =
+                make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
+                            enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
+    }
+    // ---- zero border of the padded output, this slice's 64 channels, written by the edge tiles ----
+    if (pad_w > 0 && X0 + kEcTW >= W) {
+        for (int i = tid; i < TH * pad_w * 16; i += 256) {
+            const int q = i & 15, r = i >> 4, col = r % pad_w, row = r / pad_w;
+            const int gy = Y0 + row;
+            if (gy < H) *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + W + col) * C + 64 * slice + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (pad_h > 0 && Y0 + TH >= H) {
+        const int x_end = (X0 + kEcTW >= W) ? Wo : X0 + kEcTW;   // the corner belongs to the last tile
+        for (int i = tid; i < pad_h * (x_end - X0) * 16; i += 256) {
+            const int q = i & 15, r = i >> 4, col = r % (x_end - X0), row = r / (x_end - X0);
+            *reinterpret_cast<float4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + 64 * slice + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+template <int C, int TH>
+static int conv3x3_mish_wide_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H,
+                                    int W, int pad_h, int pad_w, hipStream_t s) {
+    const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles * (C / 64) > INT32_MAX) {
+        set_error("conv3x3_mish: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((conv3x3_mish_wide_kernel<C, TH>), dim3((unsigned)(n_tiles * (C / 64))), dim3(256), 0, s,
+                       (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, pad_h, pad_w,
+                       tiles_x, tiles_y, (int)n_tiles);
+    return check_launch("conv3x3_mish_wide_kernel");
+}
+
+// ---------------------------------------------------------------------------
 // First encoder layer, enc.0.conv_a (Conv2D 3 -> 16, 3x3, stride 2, 'same', Mish; non_layers.py:402-409)
 // straight from the (B,H,W,6) input pair: Split(2) (pwcnet.py:229), the stacking of both frames on the
 // batch axis, TensorFlow's 'SAME' padding for even H, W (0 before, 1 after), the convolution, bias and
@@ -328,8 +468,14 @@ int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, voi
     else if (C == 32)
         hipLaunchKernelGGL(conv3x3_mish_kernel<32>, grid, dim3(256), 0, s, (const float*)x, (const float*)weight,
                            (const float*)bias, (float*)out, H, W, pad_h, pad_w, tiles_x, tiles_y);
+    else if (C == 64)
+        return conv3x3_mish_wide_launch<64, 4>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+    else if (C == 128)
+        return conv3x3_mish_wide_launch<128, 4>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+    else if (C == 256)
+        return conv3x3_mish_wide_launch<256, 2>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
     else {
-        set_error("conv3x3_mish: C=%d not in {16,32}", C);
+        set_error("conv3x3_mish: C=%d not in {16,32,64,128,256}", C);
         return QPWC_E_SHAPE;
     }
     return check_launch("conv3x3_mish_kernel");

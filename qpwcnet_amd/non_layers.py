@@ -255,7 +255,8 @@ class DownConv(_Weighted):
         y = _bias_mish(y, self.p("conv_b.bias"), self.p32("conv_b.bias"), self.data_format)
         return self._fmt(y), None
 
-    # own 3x3 kernel for the levels where the library runs far below the matrix peak (16 / 32 channels)
+    # own 3x3 + bias + Mish kernels (qpwc_conv3x3_mish_fwd: 16 / 32 channels with the weights in registers,
+    # 64 / 128 / 256 with a wave per 16-output block) instead of library convolution + bias/Mish pass
     hip_conv = True
 
     def _hip_s2_ok(self, padded_in):
@@ -266,7 +267,7 @@ class DownConv(_Weighted):
                 padded_in.shape[1] % 2 == 1 and padded_in.shape[2] % 2 == 1)
 
     def _hip_conv_ok(self, y_nchw):
-        return (self.hip_conv and y_nchw.dtype == torch.float32 and y_nchw.shape[1] in (16, 32) and
+        return (self.hip_conv and y_nchw.dtype == torch.float32 and y_nchw.shape[1] in (16, 32, 64, 128, 256) and
                 _hip_act_ok(y_nchw, self.data_format))
 
     def first_layer(self, pairs):

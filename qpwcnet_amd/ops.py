@@ -524,7 +524,7 @@ def conv3x3_taps(weight):
 
 
 def conv3x3_mish(x_nhwc, taps, bias, pad_h=0, pad_w=0):
-    """Mish(conv3x3_same(x) + bias) for C_in = C_out in {16, 32}, channels-last fp32 (the encoder's
+    """Mish(conv3x3_same(x) + bias) for C_in = C_out in {16, 32, 64, 128, 256}, channels-last fp32 (the encoder's
     conv_aa / conv_b, non_layers.py:410-449), written into a (B, H+pad_h, W+pad_w, C) tensor whose
     border is zero (the 'SAME' padding of a following stride-2 conv).  taps from conv3x3_taps()."""
     _check_tensor("x", x_nhwc)

@@ -303,8 +303,8 @@ def test_split_frames_pad():
     assert torch.equal(ops.split_frames_pad(x.to(DEV)).cpu(), torch.cat([x[..., :3], x[..., 3:]], dim=0))
 
 
-@pytest.mark.parametrize("C", [16, 32])
-@pytest.mark.parametrize("hw,pad", [((16, 32), 0), ((19, 37), 0), ((24, 48), 1), ((9, 17), 1)])
+@pytest.mark.parametrize("C", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("hw,pad", [((16, 32), 0), ((19, 37), 0), ((24, 48), 1), ((9, 17), 1), ((8, 16), 0)])
 def test_conv3x3_mish_encoder_kernel(C, hw, pad):
     """Encoder conv_aa / conv_b (3x3 'same' + bias + Mish, non_layers.py:410-449) on the matrix cores vs
     torch's convolution; optional zero border = the next stride-2 conv's 'SAME' padding."""
@@ -316,7 +316,7 @@ def test_conv3x3_mish_encoder_kernel(C, hw, pad):
     ref = torch_ref.mish(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1)
     out = ops.conv3x3_mish(x.to(DEV), ops.conv3x3_taps(w.to(DEV)), b.to(DEV), pad, pad).cpu()
     assert tuple(out.shape) == (3, H + pad, W + pad, C)
-    torch.testing.assert_close(out[:, :H, :W], ref, rtol=0, atol=2e-5)
+    torch.testing.assert_close(out[:, :H, :W], ref, rtol=0, atol=2e-5 if C <= 32 else 5e-5)
     if pad:
         assert float(out[:, H:].abs().max()) == 0.0 and float(out[:, :, W:].abs().max()) == 0.0
 

@@ -14,7 +14,7 @@ from sepbench import timeit  # noqa: E402
 torch.backends.cudnn.benchmark = True
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
-for C, H, W in ((16, 128, 256), (32, 64, 128)):
+for C, H, W in ((16, 128, 256), (32, 64, 128), (64, 32, 64), (128, 16, 32), (256, 8, 16)):
     x = torch.randn(16, H, W, C, device=dev, generator=g)
     w = (torch.randn(C, C, 3, 3, device=dev, generator=g) / (9 * C) ** 0.5).contiguous(memory_format=torch.channels_last)
     b = torch.randn(C, device=dev, generator=g)
