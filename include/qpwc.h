@@ -248,6 +248,11 @@ int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* 
 int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
                             int H, int W, void* stream);
 
+/* The same layer for C_in in {16, 32, 64, 128} -> 2 C_in outputs (conv_a of encoder levels 2..5):
+ * x_padded (B, H+1, W+1, C_in), weight (9, 2 C_in, C_in), bias (2 C_in), out (B, H/2, W/2, 2 C_in). */
+int qpwc_conv3x3s2_mish_c_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
+                              int H, int W, int C_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -440,6 +440,131 @@ __global__ __launch_bounds__(256, 4) void conv3x3s2_mish_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------
+// conv_a of the wide encoder levels: Conv2D(CI -> 2 CI, 3x3, stride 2, 'same', Mish) for CI = 32 / 64 / 128
+// on the zero-bordered (B, H+1, W+1, CI) output of the level before.  Work split as in
+// conv3x3_mish_wide_kernel (a wave = one block of 16 outputs for the TH x 16 output pixels of the tile,
+// 32 input channels of weights in registers at a time, next block prefetched; workgroup = 64 outputs,
+// grid = tiles x 2 CI / 64), input patch as in conv3x3s2_mish_kernel (even and odd columns in separate
+// LDS planes, so the column taps of 16 neighbouring outputs are 16 consecutive plane pixels).
+template <int CI, int TH>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_mish_wide_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ weight,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ out, int H, int W,
+                                                                     int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int CO = 2 * CI, NQ = CI / 4, NKB = CI / 32;
+    constexpr int IH = 2 * TH + 1, PW = kEcTW + 1;         // input rows of a tile; pixels per plane row
+    constexpr int NPX = IH * 33;                           // staged input pixels (33 columns)
+    constexpr int NST = (NPX * NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float in_s[2 * IH * PW * CI];   // [parity][row][col/2][CI]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int slice = blockIdx.x / n_tiles;
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * TH;               // output coordinates
+    const int Hp = H + 1, Wp = W + 1, Ho = H / 2, Wo = W / 2;
+    const int fo = 64 * slice + 16 * wave;
+    const float* xb = x + (int64_t)b * Hp * Wp * CI;
+    auto slot = [](int q, int pix) { return CI == 32 ? (q ^ ((pix >> 1) & 7)) : (q ^ (pix & 15)); };
+    // rows 2 Y0 .. + 2 TH, columns 2 X0 .. + 32 (inside the padded input or zero); all loads of a thread in
+    // flight at once (chunks of 8 cost one exposed memory latency per chunk)
+    constexpr int kChunk = NST;
+#pragma unroll
+    for (int base = 0; base < NST; base += kChunk) {
+        float4 st[kChunk];
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const int idx = tid + 256 * (base + i);
+            const int pxl = idx / NQ, q = idx - pxl * NQ;
+            const int row = pxl / 33, col = pxl - row * 33;
+            const int gy = 2 * Y0 + row, gx = 2 * X0 + col;
+            st[i] = (base + i < NST && idx < NPX * NQ && gy < Hp && gx < Wp)
+                        ? *reinterpret_cast<const float4*>(xb + ((int64_t)gy * Wp + gx) * CI + 4 * q)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const int idx = tid + 256 * (base + i);
+            const int pxl = idx / NQ, q = idx - pxl * NQ;
+            const int row = pxl / 33, col = pxl - row * 33;
+            const int pix = ((col & 1) * IH + row) * PW + (col >> 1);
+            if (base + i < NST && idx < NPX * NQ) *reinterpret_cast<float4*>(in_s + pix * CI + 4 * slot(q, pix)) = st[i];
+        }
+    }
+    f32x4e acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    f32x4e wv[9][2], wn[9][2];
+    auto load_w = [&](f32x4e (&w)[9][2], int kb) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+                w[k][kc] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)k * CO + fo + n) * CI + 32 * kb + 16 * kc + 4 * g);
+    };
+    load_w(wv, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    f32x4e bv[TH];
+#pragma unroll
+                    for (int m = 0; m < TH; ++m) {
+                        const int pix = ((kx & 1) * IH + 2 * m + ky) * PW + n + (kx >> 1);
+                        bv[m] = *reinterpret_cast<const f32x4e*>(in_s + pix * CI + 4 * slot(8 * kb + 4 * kc + g, pix));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int m = 0; m < TH; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[m][t], acc[m], 0, 0, 0);
+                }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) wv[k][kc] = wn[k][kc];
+    }
+    float* ob = out + (int64_t)b * Ho * Wo * CO;
+    const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+    for (int m = 0; m < TH; ++m) {
+        const int gy = Y0 + m, gx = X0 + n;
+        if (gy < Ho && gx < Wo)
+            *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * CO + fo + 4 * g) =
+                make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
+                            enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
+    }
+}
+
+template <int CI, int TH>
+static int conv3x3s2_mish_wide_launch(const void* x, const void* weight, const void* bias, void* out, int B,
+                                      int H, int W, hipStream_t s) {
+    const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    const int slices = 2 * CI / 64;
+    if (n_tiles * slices > INT32_MAX) {
+        set_error("conv3x3s2_mish: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((conv3x3s2_mish_wide_kernel<CI, TH>), dim3((unsigned)(n_tiles * slices)), dim3(256), 0, s,
+                       (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, tiles_x, tiles_y,
+                       (int)n_tiles);
+    return check_launch("conv3x3s2_mish_wide_kernel");
+}
+
+// CI = 16 -> conv3x3s2_mish_kernel (both output blocks in one wave); 32 / 64 / 128 -> the wide kernel
+int conv3x3s2_mish_any_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                              int CI, hipStream_t s);
+
 int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                           hipStream_t s) {
     const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + kEcTH - 1) / kEcTH;
@@ -451,6 +576,17 @@ int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, v
     hipLaunchKernelGGL(conv3x3s2_mish_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const float*)x,
                        (const float*)weight, (const float*)bias, (float*)out, H, W, tiles_x, tiles_y);
     return check_launch("conv3x3s2_mish_kernel");
+}
+
+int conv3x3s2_mish_any_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                              int CI, hipStream_t s) {
+    switch (CI) {
+        case 16: return conv3x3s2_mish_launch(x, weight, bias, out, B, H, W, s);
+        case 32: return conv3x3s2_mish_wide_launch<32, 4>(x, weight, bias, out, B, H, W, s);
+        case 64: return conv3x3s2_mish_wide_launch<64, 2>(x, weight, bias, out, B, H, W, s);
+        case 128: return conv3x3s2_mish_wide_launch<128, 2>(x, weight, bias, out, B, H, W, s);
+        default: set_error("conv3x3s2_mish: C_in=%d not in {16,32,64,128}", CI); return QPWC_E_SHAPE;
+    }
 }
 
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,

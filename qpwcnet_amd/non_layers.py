@@ -263,7 +263,8 @@ class DownConv(_Weighted):
         w = self.p("conv_a.weight")
         return (self.hip_conv and self.data_format == CHANNELS_LAST and padded_in.is_cuda and
                 padded_in.dtype == torch.float32 and padded_in.is_contiguous() and
-                tuple(w.shape) == (32, 16, 3, 3) and padded_in.shape[3] == 16 and
+                padded_in.shape[3] in (16, 32, 64, 128) and
+                tuple(w.shape) == (2 * padded_in.shape[3], padded_in.shape[3], 3, 3) and
                 padded_in.shape[1] % 2 == 1 and padded_in.shape[2] % 2 == 1)
 
     def _hip_conv_ok(self, y_nchw):

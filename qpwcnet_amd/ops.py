@@ -571,21 +571,23 @@ def first_conv_mish(pairs, taps, bias):
 
 
 def conv3x3s2_mish(x_padded, taps, bias):
-    """Mish(conv3x3 stride 2 'same' (x) + bias), 16 -> 32 channels (the second encoder level's conv_a,
-    non_layers.py:402-409) on the zero-bordered (B, H+1, W+1, 16) fp32 tensor conv3x3_mish(pad 1, 1)
-    writes, H and W even -> (B, H/2, W/2, 32).  taps = conv3x3_taps(weight) of shape (9, 32, 16)."""
+    """Mish(conv3x3 stride 2 'same' (x) + bias), C_in in {16, 32, 64, 128} -> 2 C_in channels (conv_a of encoder
+    levels 2..5, non_layers.py:402-409) on the zero-bordered (B, H+1, W+1, C_in) fp32 tensor
+    conv3x3_mish(pad 1, 1) writes, H and W even -> (B, H/2, W/2, 2 C_in).  taps = conv3x3_taps(weight) of
+    shape (9, 2 C_in, C_in)."""
     _check_tensor("x", x_padded)
-    if x_padded.dtype != torch.float32 or not x_padded.is_contiguous() or x_padded.shape[3] != 16:
-        raise ValueError("conv3x3s2_mish needs a dense fp32 (B,H+1,W+1,16) tensor")
+    ci = x_padded.shape[3]
+    if x_padded.dtype != torch.float32 or not x_padded.is_contiguous() or ci not in (16, 32, 64, 128):
+        raise ValueError("conv3x3s2_mish needs a dense fp32 (B,H+1,W+1,C) tensor, C in {16,32,64,128}")
     B, Hp, Wp, _ = x_padded.shape
     H, W = Hp - 1, Wp - 1
-    if tuple(taps.shape) != (9, 32, 16) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
-            bias.numel() != 32 or bias.dtype != torch.float32:
-        raise ValueError("taps must be fp32 (9,32,16), bias fp32 (32)")
-    out = torch.empty((B, H // 2, W // 2, 32), dtype=torch.float32, device=x_padded.device)
-    with torch.cuda.device(out.device), _timed("conv3x3s2_mish", (B, H, W, 16)):
-        rc = _hip.lib().qpwc_conv3x3s2_mish_fwd(x_padded.data_ptr(), taps.data_ptr(), bias.data_ptr(),
-                                                out.data_ptr(), B, H, W, _stream(out))
+    if tuple(taps.shape) != (9, 2 * ci, ci) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
+            bias.numel() != 2 * ci or bias.dtype != torch.float32:
+        raise ValueError("taps must be fp32 (9,{},{}), bias fp32 ({})".format(2 * ci, ci, 2 * ci))
+    out = torch.empty((B, H // 2, W // 2, 2 * ci), dtype=torch.float32, device=x_padded.device)
+    with torch.cuda.device(out.device), _timed("conv3x3s2_mish", (B, H, W, ci)):
+        rc = _hip.lib().qpwc_conv3x3s2_mish_c_fwd(x_padded.data_ptr(), taps.data_ptr(), bias.data_ptr(),
+                                                  out.data_ptr(), B, H, W, ci, _stream(out))
     _hip.check(rc)
     return out
 
