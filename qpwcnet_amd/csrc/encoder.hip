@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3s2_mish_kernel(const float* __r
 // grid = tiles x 2 CI / 64), input patch as in conv3x3s2_mish_kernel (even and odd columns in separate
 // LDS planes, so the column taps of 16 neighbouring outputs are 16 consecutive plane pixels).
 template <int CI, int TH>
-__global__ __launch_bounds__(256, 2) void conv3x3s2_mish_wide_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256, (2 * (2 * TH + 1) * (kEcTW + 1) * CI * 4 > 80 * 1024) ? 1 : 2) void conv3x3s2_mish_wide_kernel(const float* __restrict__ x,
                                                                      const float* __restrict__ weight,
                                                                      const float* __restrict__ bias,
                                                                      float* __restrict__ out, int H, int W,
