@@ -193,9 +193,23 @@ class UpConv(_Weighted):
         y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), None, stride=2, padding=1)
         return self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.p32("conv_up.bias"), self.data_format))
 
-    def cat_skip(self, x, skip):
+    def cat_skip(self, x, skip, batch_chunks=1):
         """concat([UpConv(x), skip]) on the channel axis (pwcnet.py:186-195).  On the HIP path the
         activation epilogue writes its half straight into the concat buffer."""
+        # batch_chunks > 1: the transposed convolution as that many launches over slices of the batch (what
+        # pwcnet._forward_two_streams asks for when this runs on the side stream beside the coarse flow levels)
+        nsplit = int(batch_chunks)
+        if (nsplit > 1 and self.data_format == CHANNELS_LAST and x.is_cuda and x.shape[0] % nsplit == 0 and
+                skip.shape[3] % 4 == 0 and x.dtype in (torch.float32, torch.float16)):
+            w = self.p("conv_up.weight")
+            c1, c2 = w.shape[1], skip.shape[3]
+            buf = torch.empty(skip.shape[:3] + (c1 + c2,), dtype=x.dtype, device=x.device)
+            nb = x.shape[0] // nsplit
+            for i in range(nsplit):
+                yh = F.conv_transpose2d(self._nchw(x[i * nb:(i + 1) * nb]), w, None, stride=2, padding=1)
+                ops.bias_mish_into(yh.permute(0, 2, 3, 1), self.p32("conv_up.bias"), buf[i * nb:(i + 1) * nb], 0)
+            buf[..., c1:] = skip
+            return buf
         y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), None, stride=2, padding=1)
         if _hip_act_ok(y, self.data_format) and skip.shape[3] % 4 == 0:
             c1, c2 = y.shape[1], skip.shape[3]
