@@ -385,27 +385,30 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 }
                 p += (int64_t)b * H * W * ps + cc;
             }
-            if (left >= 4 || left == 0) {
-                // branch-free: halo pixels outside the image (and channels past C) read a 16-byte block of
-                // zeros; pixel offset x pixel stride is a 24-bit multiply (the launcher checks H*W < 2^24)
+            {
+                // branch-free: halo pixels outside the image, channels past C and the lanes of a short last
+                // source (fixed up below) read a 16-byte block of zeros; pixel offset x pixel stride is a
+                // 24-bit multiply (the launcher checks H*W < 2^24)
+                const bool full = left >= 4;
 #pragma unroll
                 for (int it = 0; it < NST; ++it) {
-                    const bool ok = goff[it] >= 0 && left > 0;
+                    const bool ok = goff[it] >= 0 && full;
                     const float* q = ok ? p : kScZeros;
                     const unsigned off = ok ? __umul24((unsigned)goff[it], (unsigned)ps) : 0u;
                     st4[it] = *reinterpret_cast<const float4*>(q + off);
                 }
-            } else {
+            }
+            // a short last source (Flow/UpFlow's 2-channel flow): element loads, once per launch, behind ONE
+            // wave-uniform branch (per-lane branches here cost 26 exec-mask sequences in every step)
+            const bool tail = left > 0 && left < 4;
+            if (__builtin_amdgcn_ballot_w64(tail) != 0) {
+                const int i1 = left > 1 ? 1 : 0, i2 = left > 2 ? 2 : 0;   // never past the source's channels
 #pragma unroll
                 for (int it = 0; it < NST; ++it) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (goff[it] >= 0) {
-                        const float* q = p + __umul24((unsigned)goff[it], (unsigned)ps);
-                        v.x = q[0];
-                        if (left > 1) v.y = q[1];
-                        if (left > 2) v.z = q[2];
-                    }
-                    st4[it] = v;
+                    const bool ok = tail && goff[it] >= 0;
+                    const float* q = ok ? p + __umul24((unsigned)(ok ? goff[it] : 0), (unsigned)ps) : kScZeros;
+                    const float e0 = q[0], e1 = q[ok ? i1 : 0], e2 = q[ok ? i2 : 0];
+                    if (tail) st4[it] = make_float4(ok ? e0 : 0.f, (ok && left > 1) ? e1 : 0.f, (ok && left > 2) ? e2 : 0.f, 0.f);
                 }
             }
         }
