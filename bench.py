@@ -152,7 +152,9 @@ def main():
     # The one collective of the path: an all-gather of the 6 per-level EPE (+ shard weight) per step.
     # On RCCL it is asynchronous: the exchange of step k travels while step k+1 computes, and its result
     # is consumed (the stream waits for it) one step later; the last one is drained inside the timed region.
-    gather = None if args.dist_backend == "gloo" else qdist.EpeGather(6, dev, n_local=B)
+    # (CPU rehearsal of the N > 1 path, --dist-backend gloo: the same submit/collect pattern on host tensors)
+    gloo = args.dist_backend == "gloo"
+    gather = qdist.EpeGather(6, "cpu" if gloo else dev, n_local=B)
 
     def step():
         if graph is not None:
@@ -160,14 +162,12 @@ def main():
             e = epe_local
         else:
             _, e = forward()
-        if gather is None:   # CPU rehearsal of the N > 1 path
-            return qdist.gather_epe(e.cpu(), B)
-        gather.submit(e)
+        gather.submit(e.cpu() if gloo else e)
         return gather.collect() if gather.outstanding() > 1 else None
 
     def drain():
         out = None
-        while gather is not None and gather.outstanding():
+        while gather.outstanding():
             out = gather.collect()
         return out
 
