@@ -253,6 +253,14 @@ int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void
 int qpwc_conv3x3s2_mish_c_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
                               int H, int W, int C_in, void* stream);
 
+/* UpConv of the decoder (non_layers.py:196-210): Conv2DTranspose(F, 4x4, strides 2, padding='same') + bias +
+ * Mish of x (B,H,W,C), C in {64,128,256}, F % 16 == 0, written into channels [0, F) of `out`
+ * (B, 2H, 2W, *) whose pixels are out_pixel_stride floats apart -- with out_pixel_stride = F + C_skip this is
+ * the `up` half of the decoder's concat([up, skip]) (pwcnet.py:186-195) in place.
+ * weight: (16, F, C) fp32 = [ky*4+kx][out][in] (torch ConvTranspose2d weight (C,F,4,4) permuted (2,3,1,0)). */
+int qpwc_upconv4x4s2_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                              int C, int F, int64_t out_pixel_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

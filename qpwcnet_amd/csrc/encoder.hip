@@ -282,6 +282,139 @@ static int conv3x3_mish_wide_launch(const void* x, const void* weight, const voi
 }
 
 // ---------------------------------------------------------------------------
+// UpConv of the decoder (non_layers.py:196-210): Conv2DTranspose(F, 4x4, stride 2, 'same') + bias + Mish,
+// written straight into channels [0, F) of the concat([up, skip]) buffer (pwcnet.py:186-195).
+// out[2y+py, 2x+px] only sees the 2 x 2 taps of the 4 x 4 kernel that match its parity:
+//   py = 0: (input row y, ky = 1), (y-1, ky = 3);   py = 1: (y, ky = 2), (y+1, ky = 0);   same in x,
+// i.e. four independent 2x2 convolutions (K = 4 C) over the same input tile.  Workgroup = 4 waves = the 4
+// parities of ONE block of 16 outputs for a TH x 16 input tile (grid = tiles x F/16); a wave keeps its 4
+// taps x 32 input channels of weights in 32 registers (next block prefetched), every B operand is one
+// ds_read_b128 of the (TH+2) x 18 halo tile (pixels = C floats, chunk q at q ^ (p & 15)).
+// No zero-fill launch, no separate bias/Mish pass, short workgroups (512 matrix instructions per wave).
+// (Resident workgroups walking the tiles behind a capped grid: 1.294 ms/step at 256, 1.262 at 384 workgroups,
+// against 1.257 for four plain launches over quarters of the batch -- see UpConv.cat_skip.)
+// weight: [ky*4+kx][F][C] fp32.
+template <int C, int TH>
+__global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ weight,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ out, int H, int W, int F,
+                                                                  int out_pixel_stride, int tiles_x, int tiles_y,
+                                                                  int n_tiles) {
+    constexpr int NQ = C / 4, NKB = C / 32;
+    constexpr int HH = TH + 2, NH = HH * kEcHW;
+    constexpr int NST = (NH * NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float in_s[NH * C];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int fblk = blockIdx.x / n_tiles;
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * TH;
+    const int fo = 16 * fblk;
+    const float* xb = x + (int64_t)b * H * W * C;
+    {
+        float4 st[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            st[it] = (idx < NH * NQ && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                         ? *reinterpret_cast<const float4*>(xb + ((int64_t)gy * W + gx) * C + 4 * q)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            if (idx < NH * NQ) *reinterpret_cast<float4*>(in_s + hp * C + 4 * (q ^ (hp & 15))) = st[it];
+        }
+    }
+    // the 2 x 2 taps of this wave's parity: input offset (dy, dx), kernel position (ky, kx)
+    const int dy1 = py ? 1 : -1, dx1 = px ? 1 : -1;          // second tap; the first is offset 0
+    const int ky0 = py ? 2 : 1, ky1 = py ? 0 : 3, kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
+    const int kpos[4] = {ky0 * 4 + kx0, ky0 * 4 + kx1, ky1 * 4 + kx0, ky1 * 4 + kx1};
+    const int offy[4] = {0, 0, dy1, dy1}, offx[4] = {0, dx1, 0, dx1};
+    f32x4e acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    f32x4e wv[4][2], wn[4][2];
+    auto load_w = [&](f32x4e (&w)[4][2], int kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+                w[t][kc] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)kpos[t] * F + fo + n) * C + 32 * kb + 16 * kc + 4 * g);
+    };
+    load_w(wv, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                f32x4e bv[TH];
+#pragma unroll
+                for (int m = 0; m < TH; ++m) {
+                    const int hp = (m + 1 + offy[t]) * kEcHW + n + 1 + offx[t];
+                    bv[m] = *reinterpret_cast<const f32x4e*>(in_s + hp * C + 4 * ((8 * kb + 4 * kc + g) ^ (hp & 15)));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < TH; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][kc][j], bv[m][j], acc[m], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) wv[t][kc] = wn[t][kc];
+    }
+    const int H2 = 2 * H, W2 = 2 * W;
+    float* ob = out + (int64_t)b * H2 * W2 * out_pixel_stride;
+    const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+    for (int m = 0; m < TH; ++m) {
+        const int gy = Y0 + m, gx = X0 + n;
+        if (gy < H && gx < W)
+            *reinterpret_cast<float4*>(ob + ((int64_t)(2 * gy + py) * W2 + 2 * gx + px) * out_pixel_stride + fo + 4 * g) =
+                make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
+                            enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
+    }
+}
+
+template <int C, int TH>
+static int upconv_launch_t(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int F,
+                           int out_pixel_stride, hipStream_t s) {
+    const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles * (F / 16) > INT32_MAX) {
+        set_error("upconv4x4s2_mish: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((upconv4x4s2_mish_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), 0, s,
+                       (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, F,
+                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles);
+    return check_launch("upconv4x4s2_mish_kernel");
+}
+
+int upconv4x4s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int C,
+                            int F, int out_pixel_stride, hipStream_t s) {
+    switch (C) {
+        case 64: return upconv_launch_t<64, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 128: return upconv_launch_t<128, 4>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 256: return upconv_launch_t<256, 2>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        default: set_error("upconv4x4s2_mish: C=%d not in {64,128,256}", C); return QPWC_E_SHAPE;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // First encoder layer, enc.0.conv_a (Conv2D 3 -> 16, 3x3, stride 2, 'same', Mish; non_layers.py:402-409)
 // straight from the (B,H,W,6) input pair: Split(2) (pwcnet.py:229), the stacking of both frames on the
 // batch axis, TensorFlow's 'SAME' padding for even H, W (0 before, 1 after), the convolution, bias and

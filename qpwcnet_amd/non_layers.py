@@ -193,10 +193,35 @@ class UpConv(_Weighted):
         y = F.conv_transpose2d(self._nchw(x), self.p("conv_up.weight"), None, stride=2, padding=1)
         return self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.p32("conv_up.bias"), self.data_format))
 
-    def cat_skip(self, x, skip, batch_chunks=1):
+    hip_upconv = True
+
+    def _hip_upconv_ok(self, x, skip):
+        w = self.p("conv_up.weight")
+        return (self.hip_upconv and self.data_format == CHANNELS_LAST and x.is_cuda and x.dtype == torch.float32 and
+                x.is_contiguous() and x.shape[3] in (64, 128, 256) and w.shape[0] == x.shape[3] and
+                w.shape[1] % 16 == 0 and tuple(w.shape[2:]) == (4, 4) and skip.shape[3] % 4 == 0 and
+                tuple(skip.shape[1:3]) == (2 * x.shape[1], 2 * x.shape[2]))
+
+    def cat_skip(self, x, skip, batch_chunks=1, hip_chunks=1):
         """concat([UpConv(x), skip]) on the channel axis (pwcnet.py:186-195).  On the HIP path the
         activation epilogue writes its half straight into the concat buffer."""
-        # batch_chunks > 1: the transposed convolution as that many launches over slices of the batch (what
+        if self._hip_upconv_ok(x, skip):
+            # own transposed-convolution kernel: bias + Mish fused, written straight into the concat buffer
+            key = self.prefix + "#taps_up"
+            t = self.params.get(key)
+            if t is None:
+                t = self.params[key] = ops.upconv_taps(self.p("conv_up.weight"))
+            buf = torch.empty(skip.shape[:3] + (t.shape[1] + skip.shape[3],), dtype=x.dtype, device=x.device)
+            nch = int(hip_chunks)
+            if nch > 1 and x.shape[0] % nch == 0:
+                nb = x.shape[0] // nch
+                for i in range(nch):
+                    ops.upconv4x4s2_mish_into(x[i * nb:(i + 1) * nb], t, self.p32("conv_up.bias"), buf[i * nb:(i + 1) * nb])
+            else:
+                ops.upconv4x4s2_mish_into(x, t, self.p32("conv_up.bias"), buf)
+            buf[..., t.shape[1]:] = skip
+            return buf
+        # (library path) batch_chunks > 1: the transposed convolution as that many launches over slices of the batch (what
         # pwcnet._forward_two_streams asks for when this runs on the side stream beside the coarse flow levels)
         nsplit = int(batch_chunks)
         if (nsplit > 1 and self.data_format == CHANNELS_LAST and x.is_cuda and x.shape[0] % nsplit == 0 and

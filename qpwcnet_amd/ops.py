@@ -592,6 +592,34 @@ def conv3x3s2_mish(x_padded, taps, bias):
     return out
 
 
+def upconv_taps(weight):
+    """torch ConvTranspose2d weight (C_in, F, 4, 4) -> the (16, F, C_in) fp32 layout of qpwc_upconv4x4s2_mish_fwd."""
+    return weight.float().permute(2, 3, 1, 0).reshape(16, weight.shape[1], weight.shape[0]).contiguous()
+
+
+def upconv4x4s2_mish_into(x_nhwc, taps, bias, dst):
+    """Mish(Conv2DTranspose(4x4, stride 2, 'same')(x) + bias) (the decoder's UpConv, non_layers.py:196-210)
+    written into channels [0, F) of the dense channels-last buffer dst (B, 2H, 2W, Ctot >= F): the `up` half of
+    concat([up, skip]) (pwcnet.py:186-195).  taps from upconv_taps().  Returns dst."""
+    _check_tensor("x", x_nhwc)
+    _check_tensor("dst", dst)
+    if x_nhwc.dtype != torch.float32 or dst.dtype != torch.float32 or not x_nhwc.is_contiguous() or \
+            not dst.is_contiguous():
+        raise ValueError("upconv4x4s2_mish_into needs dense fp32 channels-last tensors")
+    B, H, W, C = x_nhwc.shape
+    F_ = taps.shape[1]
+    if tuple(taps.shape) != (16, F_, C) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
+            bias.numel() != F_ or bias.dtype != torch.float32:
+        raise ValueError("taps must be fp32 (16,F,{}), bias fp32 (F)".format(C))
+    if tuple(dst.shape[:3]) != (B, 2 * H, 2 * W) or dst.shape[3] < F_:
+        raise ValueError("dst must be (B,2H,2W,Ctot) with Ctot >= F")
+    with torch.cuda.device(dst.device), _timed("upconv4x4s2_mish", (B, H, W, C, F_)):
+        rc = _hip.lib().qpwc_upconv4x4s2_mish_fwd(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(), dst.data_ptr(),
+                                                  B, H, W, C, F_, dst.shape[3], _stream(dst))
+    _hip.check(rc)
+    return dst
+
+
 def bias_mish_pad(x_nhwc, bias, pad_h, pad_w):
     """Mish(x + bias) written into a new (B, H+pad_h, W+pad_w, C) tensor whose border is zero:
     the activation epilogue and TensorFlow's 'SAME' padding of the following stride-2 conv

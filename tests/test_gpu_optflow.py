@@ -293,6 +293,26 @@ def test_bias_mish_into_concat_buffer():
         ops.bias_mish_into(x.to(DEV), b.to(DEV), dst, 30)
 
 
+@pytest.mark.parametrize("C,F", [(64, 16), (128, 32), (256, 64), (256, 128)])
+@pytest.mark.parametrize("hw", [(8, 16), (19, 37), (5, 9)])
+def test_upconv4x4s2_mish_into_concat_buffer(C, F, hw):
+    """Decoder UpConv (Conv2DTranspose 4x4 stride 2 'same' + bias + Mish, non_layers.py:196-210) written into
+    the `up` half of the concat buffer vs torch's transposed convolution; the skip half stays untouched."""
+    rng = np.random.default_rng(C + F + hw[0])
+    H, W = hw
+    x = _rand(rng, 2, H, W, C)
+    w = _rand(rng, C, F, 4, 4) / np.sqrt(4 * C)
+    b = _rand(rng, F)
+    ref = torch_ref.mish(torch.nn.functional.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=1))
+    ref = ref.permute(0, 2, 3, 1)
+    dst = torch.full((2, 2 * H, 2 * W, F + 24), 7.0, device=DEV)
+    ops.upconv4x4s2_mish_into(x.to(DEV), ops.upconv_taps(w.to(DEV)), b.to(DEV), dst)
+    torch.testing.assert_close(dst[..., :F].cpu(), ref, rtol=0, atol=5e-5)
+    assert bool((dst[..., F:] == 7.0).all())
+    with pytest.raises(ValueError):
+        ops.upconv4x4s2_mish_into(x.to(DEV), ops.upconv_taps(w.to(DEV)), b.to(DEV), dst[:, :-1].contiguous())
+
+
 def test_split_frames_pad():
     rng = np.random.default_rng(8)
     x = _rand(rng, 3, 10, 12, 6)
