@@ -185,12 +185,14 @@ class QpwcNet:
         # critical-path kernels beside it wait for CUs; two launches of B frames each leave room for them
         # (B=8: 1.343 -> 1.309 ms/step; 4 chunks: no further gain; B=32: the launches are multi-round anyway, -1 %)
         # (own transposed-convolution kernel: four launches over quarters of the batch, 256 short-lived workgroups
-        # each = one per CU: 1.308 -> 1.257 ms/step; 8 / 16 launches: 1.43 / 1.95)
+        # each = one per CU: 1.308 -> 1.257 ms/step; 8 / 16 launches: 1.43 / 1.95; two launches for the coarsest
+        # level, whose quarter launches are only 128 workgroups: another -0.7 %)
         small = encs[-1].shape[0] <= 32
-        chunks, hip_chunks = (2, 4) if small else (1, 1)
+        chunks = 2 if small else 1
         with torch.cuda.stream(side):
             f, i = encs[-1], -2
-            for l in self.dec:
+            for li, l in enumerate(self.dec):
+                hip_chunks = (2 if li == 0 else 4) if small else 1
                 f = l.cat_skip(f, encs[i], batch_chunks=chunks, hip_chunks=hip_chunks)
                 i -= 1
                 decs.append(f)
