@@ -14,7 +14,11 @@ network to install them).  What pins the restatement instead:
   (``qpwcnet/core/layers.py:72-100``) and restated here op for op;
 * the reference's own invariant ``CostVolume == CostVolumeV2``
   (``qpwcnet/app/test/test_cvol_equal.py:25``) makes that source the spec for
-  the tfa ``CorrelationCost`` variant as well;
+  the tfa ``CorrelationCost`` variant as well; the tfa op (third-party,
+  ``tensorflow_addons``, version unpinned) is ALSO restated on its own from its
+  published algorithm in ``oracle/tfa_ref.py`` / ``oracle_correlation_cost`` (C), the
+  two restatements are asserted equal at the reference's shapes, and the GPU
+  ``CostVolumeV2`` is tested against that one;
 * ``tf_warp`` (``qpwcnet/core/warp.py:63-153``) is in-tree and restated op for
   op; ``WarpV2`` follows the in-tree copy of tfa ``dense_image_warp``
   (``qpwcnet/core/warp.py:156-211``) plus the published algorithm of

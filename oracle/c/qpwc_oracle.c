@@ -141,4 +141,52 @@ double oracle_epe(const float* a, const float* b, int B, int H, int W) {
     return s / (double)n;
 }
 
-int oracle_version(void) { return 1; }
+/* tensorflow-addons CorrelationCost (the op behind CostVolumeV2, layers.py:124-132), CPU
+ * functor restated loop for loop from its published algorithm (tensorflow_addons, version
+ * unpinned by the reference; see oracle/tfa_ref.py for the statement and its caveats).
+ * fp32 accumulation in the op's order (kernel rows, kernel cols, channels), then /= K.
+ * The op's output is NCHW; out_layout 0 applies the Keras layer's transpose to NHWC.
+ * in_layout: 0 = NHWC, 1 = NCHW.  apply_lrelu != 0 adds CostVolumeV2's leaky_relu(0.1). */
+int oracle_correlation_cost(const float* a, const float* b, float* out, int N, int H, int W, int C,
+                            int kernel_size, int max_displacement, int stride_1, int stride_2,
+                            int pad, int in_layout, int out_layout, int apply_lrelu) {
+    if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return -1;
+    if (kernel_size % 2 != 1 || stride_1 < 1 || stride_2 < 1) return -2;
+    const int kernel_rad = (kernel_size - 1) / 2;
+    const int border = max_displacement + kernel_rad;
+    const int oH = (int)ceil((double)(H + 2 * pad - 2 * border) / (double)stride_1);
+    const int oW = (int)ceil((double)(W + 2 * pad - 2 * border) / (double)stride_1);
+    if (oH < 1 || oW < 1) return -3;
+    const int disp_rad = max_displacement / stride_2;
+    const int disp_size = 2 * disp_rad + 1, oC = disp_size * disp_size;
+    const float K = (float)(kernel_size * kernel_size * C);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int h = 0; h < oH; ++h) {
+            const int h1 = (h - pad) * stride_1 + max_displacement + kernel_rad;
+            for (int w = 0; w < oW; ++w) {
+                const int w1 = (w - pad) * stride_1 + max_displacement + kernel_rad;
+                for (int tj = -disp_rad; tj <= disp_rad; ++tj)
+                    for (int ti = -disp_rad; ti <= disp_rad; ++ti) {
+                        const int tc = (tj + disp_rad) * disp_size + (ti + disp_rad);
+                        const int w2 = w1 + ti * stride_2, h2 = h1 + tj * stride_2;
+                        float acc = 0.0f;
+                        for (int j = -kernel_rad; j <= kernel_rad; ++j) {
+                            if (h1 + j < 0 || h1 + j >= H || h2 + j < 0 || h2 + j >= H) continue;
+                            for (int i = -kernel_rad; i <= kernel_rad; ++i) {
+                                if (w1 + i < 0 || w1 + i >= W || w2 + i < 0 || w2 + i >= W) continue;
+                                for (int c = 0; c < C; ++c)
+                                    acc += a[idx(in_layout, H, W, C, n, h1 + j, w1 + i, c)] *
+                                           b[idx(in_layout, H, W, C, n, h2 + j, w2 + i, c)];
+                            }
+                        }
+                        acc /= K;
+                        if (apply_lrelu) acc = acc > 0.0f ? acc : acc * 0.1f;
+                        out[idx(out_layout, oH, oW, oC, n, h, w, tc)] = acc;
+                    }
+            }
+        }
+    return 0;
+}
+
+int oracle_version(void) { return 2; }

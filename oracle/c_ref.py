@@ -34,6 +34,8 @@ def lib():
         L.oracle_warp.restype = ctypes.c_int
         L.oracle_epe.argtypes = [fp, fp] + [ctypes.c_int] * 3
         L.oracle_epe.restype = ctypes.c_double
+        L.oracle_correlation_cost.argtypes = [fp, fp, fp] + [ctypes.c_int] * 12
+        L.oracle_correlation_cost.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -96,3 +98,31 @@ def epe(a, b):
     b = np.ascontiguousarray(b, dtype=np.float32)
     B, H, W, _ = a.shape
     return lib().oracle_epe(_fp(a), _fp(b), B, H, W)
+
+
+def correlation_cost(input_a, input_b, kernel_size=1, max_displacement=4, stride_1=1, stride_2=1, pad=4,
+                     data_format="channels_last", lrelu=False):
+    """tfa CorrelationCost, scalar C loop (oracle/tfa_ref.py states the algorithm); with
+    ``lrelu`` the whole of CostVolumeV2.call (qpwcnet/core/layers.py:128-132)."""
+    import math
+    a = np.ascontiguousarray(input_a, dtype=np.float32)
+    b = np.ascontiguousarray(input_b, dtype=np.float32)
+    if a.shape != b.shape:
+        raise ValueError("input_a and input_b must have the same shape")
+    B, H, W, C, layout = _dims(a.shape, data_format)
+    border = max_displacement + (kernel_size - 1) // 2
+    oH = int(math.ceil((H + 2 * pad - 2 * border) / float(stride_1)))
+    oW = int(math.ceil((W + 2 * pad - 2 * border) / float(stride_1)))
+    ds = 2 * (max_displacement // stride_2) + 1
+    shape = (B, oH, oW, ds * ds) if layout == 0 else (B, ds * ds, oH, oW)
+    out = np.empty(shape, dtype=np.float32)
+    rc = lib().oracle_correlation_cost(_fp(a), _fp(b), _fp(out), B, H, W, C, kernel_size, max_displacement,
+                                       stride_1, stride_2, pad, layout, layout, int(lrelu))
+    if rc != 0:
+        raise ValueError("oracle_correlation_cost rc={}".format(rc))
+    return out
+
+
+def cost_volume_v2(prv, nxt, search_range=4, data_format="channels_last"):
+    r = int(search_range)
+    return correlation_cost(prv, nxt, 1, r, 1, 1, r, data_format, lrelu=True)

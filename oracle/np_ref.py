@@ -29,12 +29,15 @@ def leaky_relu(x, alpha=0.1):
     return np.where(x > 0, x, x * np.asarray(alpha, dtype=x.dtype))
 
 
-def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST):
+def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST, activation=True):
     """``CostVolume.call`` -- qpwcnet/core/layers.py:72-100
     (twin: qpwcnet/core/non_layers.py:72-104).
 
     ``CostVolumeV2`` (layers.py:128-132) is the same function by the reference's
-    own invariant (app/test/test_cvol_equal.py:25).
+    own invariant (app/test/test_cvol_equal.py:25); its own arithmetic (the tfa
+    CorrelationCost op) is restated independently in ``oracle/tfa_ref.py``.
+    ``activation=False`` stops before the LeakyReLU of layers.py:99 (what the tfa op
+    itself returns, for comparing the two restatements).
     """
     prv = np.asarray(prv)
     nxt = np.asarray(nxt)
@@ -57,6 +60,8 @@ def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST):
             cost = np.mean(prv * roi, axis=axis, keepdims=True, dtype=prv.dtype)  # :94
             cost_vol.append(cost)
     cost_vol = np.concatenate(cost_vol, axis=axis)              # layers.py:96
+    if not activation:
+        return cost_vol
     return leaky_relu(cost_vol, 0.1)                            # layers.py:99
 
 

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import cases
-from oracle import c_ref, np_ref, net_ref, torch_ref
+from oracle import c_ref, np_ref, net_ref, tfa_ref, torch_ref
 from qpwcnet_amd import layers, non_layers, ops, synth, warp as warp_mod
 from qpwcnet_amd.backend import image_data_format, set_image_data_format
 from qpwcnet_amd.pwcnet import build_flower
@@ -70,21 +70,39 @@ def test_warp_is_bit_exact_against_the_unfused_c_oracle():
         np.testing.assert_array_equal(out, _oracle_f32(name), err_msg=name)
 
 
-def test_reference_invariant_v1_equals_v2():
-    """qpwcnet/app/test/test_cvol_equal.py:9-25: (v0 - v1).sum() == 0.0, both layouts."""
+@pytest.mark.parametrize("mod", [layers, non_layers], ids=["layers", "non_layers"])
+@pytest.mark.parametrize("cn,shape", [("channels_last", (4, 32, 64, 3)), ("channels_first", (4, 3, 32, 64)),
+                                      ("channels_last", (1, 128, 256, 3)), ("channels_first", (1, 3, 128, 256))])
+def test_cost_volume_v2_against_the_tfa_correlation_cost_restatement(mod, cn, shape):
+    """A2: CostVolumeV2 (the variant the network instantiates, use_tfa=True) against the INDEPENDENT
+    restatement of tfa CorrelationCost(1, 4, 1, 1, 4) + leaky_relu (oracle/tfa_ref.py; layers.py:124-132)
+    at the reference's own shapes (test/test_cost_volume.py:16-21, app/test/test_cvol_equal.py:11), and
+    CostVolume (V1) against the in-tree restatement; the reference's printed sum of differences V1 - V2
+    (test_cvol_equal.py:25) is checked between the two ORACLES in tests/test_oracle.py, not between two
+    names of one kernel."""
     fmt0 = image_data_format()
     try:
-        for cn in ("channels_first", "channels_last"):
-            set_image_data_format(cn)
-            shape = (1, 3, 128, 256) if cn == "channels_first" else (1, 128, 256, 3)
-            rng = np.random.default_rng(99)
-            prv, nxt = rng.standard_normal(shape).astype(np.float32), rng.standard_normal(shape).astype(np.float32)
-            v0 = layers.CostVolume(4)((gpu(prv), gpu(nxt)))
-            v1 = layers.CostVolumeV2(4)((gpu(prv), gpu(nxt)))
-            assert float((v0 - v1).sum()) == 0.0
-            np.testing.assert_allclose(v0.cpu().numpy(), np_ref.cost_volume(prv, nxt, 4, cn), atol=TOL)
+        set_image_data_format(cn)   # the layers read the global at construction (layers.py:41)
+        rng = np.random.default_rng(99)
+        prv, nxt = rng.standard_normal(shape).astype(np.float32), rng.standard_normal(shape).astype(np.float32)
+        v2 = mod.CostVolumeV2(4)((gpu(prv), gpu(nxt))).cpu().numpy()
+        v1 = mod.CostVolume(4)((gpu(prv), gpu(nxt))).cpu().numpy()
     finally:
         set_image_data_format(fmt0)
+    np.testing.assert_allclose(v2, tfa_ref.cost_volume_v2(prv, nxt, 4, cn), rtol=0, atol=TOL)
+    np.testing.assert_allclose(v2, c_ref.cost_volume_v2(prv, nxt, 4, cn), rtol=0, atol=TOL)
+    np.testing.assert_allclose(v1, np_ref.cost_volume(prv, nxt, 4, cn), rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("name", ["cv_L0", "cv_L1", "cv_L2", "cv_L3", "cv_L4", "cv_ragged", "cv_r2"])
+def test_cost_volume_v2_level_shapes_against_tfa_restatement(name):
+    """The same at the five 256x512 level shapes (every matrix-core kernel path), a ragged shape and
+    search_range 2 -> CorrelationCost(1, 2, 1, 1, 2): scalar C loop of the published tfa algorithm."""
+    op, fmt, shape, seed, extra = cases.CASES[name]
+    r = extra.get("search_range", 4)
+    a, b = cases.make_inputs(name)
+    out = non_layers.CostVolumeV2(search_range=r, data_format=fmt)((gpu(a), gpu(b))).cpu().numpy()
+    np.testing.assert_allclose(out, c_ref.cost_volume_v2(a, b, r, fmt), rtol=0, atol=TOL)
 
 
 def test_known_answer_3x3_and_broadcast_flow():

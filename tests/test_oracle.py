@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import cases
-from oracle import np_ref, torch_ref
+from oracle import np_ref, tfa_ref, torch_ref
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -238,3 +238,72 @@ def test_occlusion_known_answers_and_layouts():
                           np_ref.estimate_occlusion_map(nchw, "channels_first"))
     with pytest.raises(ValueError):
         np_ref.estimate_occlusion_map(flow[0])
+
+
+# ---- A2: tfa CorrelationCost restated on its own (oracle/tfa_ref.py) ---------------------------
+# The reference's claim (qpwcnet/app/test/test_cvol_equal.py:9-25, test/test_cost_volume.py:16-24):
+# CostVolume (in-tree pure TF) and CostVolumeV2 (tfa CorrelationCost(1, 4, 1, 1, 4)) print a summed
+# difference of 0.  Here: the two independent RESTATEMENTS agree, at the reference's own shapes.
+_CVEQ_SHAPES = [((4, 32, 64, 3), "channels_last"), ((4, 3, 32, 64), "channels_first"),
+                ((1, 128, 256, 3), "channels_last"), ((1, 3, 128, 256), "channels_first")]
+
+
+@pytest.mark.parametrize("shape,fmt", _CVEQ_SHAPES)
+def test_tfa_correlation_cost_equals_in_tree_cost_volume_before_lrelu(c_oracle, shape, fmt):
+    rng = np.random.default_rng(77)
+    prv = rng.standard_normal(shape).astype(np.float32)   # tf.random.normal, test_cost_volume.py:20-21
+    nxt = rng.standard_normal(shape).astype(np.float32)
+    v1 = np_ref.cost_volume(prv, nxt, 4, fmt, activation=False)
+    v2 = tfa_ref.correlation_cost(prv, nxt, 1, 4, 1, 1, 4, fmt)
+    assert v1.shape == v2.shape
+    np.testing.assert_allclose(v2, v1, rtol=0, atol=1e-6)
+    assert abs(float((v1 - v2).sum())) <= 1e-5            # what test_cvol_equal.py:25 prints
+    # float64: the two op orders differ only by rounding
+    v1d = np_ref.cost_volume(prv.astype(np.float64), nxt.astype(np.float64), 4, fmt, activation=False)
+    v2d = tfa_ref.correlation_cost(prv.astype(np.float64), nxt.astype(np.float64), 1, 4, 1, 1, 4, fmt)
+    np.testing.assert_allclose(v2d, v1d, rtol=0, atol=1e-14)
+    # C scalar loop == numpy form of the same published algorithm; and with the layer's LeakyReLU
+    np.testing.assert_allclose(c_oracle.correlation_cost(prv, nxt, data_format=fmt), v2, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c_oracle.cost_volume_v2(prv, nxt, 4, fmt), np_ref.cost_volume(prv, nxt, 4, fmt),
+                               rtol=0, atol=1e-6)
+    np.testing.assert_allclose(tfa_ref.cost_volume_v2(prv, nxt, 4, fmt), np_ref.cost_volume(prv, nxt, 4, fmt),
+                               rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+@pytest.mark.parametrize("ks,md,s1,s2,pad", [(1, 4, 1, 1, 4), (3, 2, 1, 1, 2), (1, 4, 1, 2, 4), (3, 4, 2, 2, 4),
+                                             (1, 2, 1, 1, 0)])
+def test_tfa_correlation_cost_three_forms_agree(c_oracle, fmt, ks, md, s1, s2, pad):
+    """Scalar 7-deep loop (the published functor, literally) == vectorised numpy form == C loop, also
+    away from the reference's arguments (kernel window, strides, no padding)."""
+    rng = np.random.default_rng(ks * 100 + md * 10 + s2)
+    shape = (2, 6, 7, 3) if fmt == "channels_last" else (2, 3, 6, 7)
+    a = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape).astype(np.float32)
+    loops = tfa_ref.correlation_cost_loops(a, b, ks, md, s1, s2, pad, fmt)
+    np.testing.assert_allclose(tfa_ref.correlation_cost(a, b, ks, md, s1, s2, pad, fmt), loops, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c_oracle.correlation_cost(a, b, ks, md, s1, s2, pad, fmt), loops, rtol=0, atol=1e-6)
+
+
+def test_tfa_correlation_cost_known_answers():
+    """Channel (tj+4)*9 + (ti+4) with tj the ROW displacement: a one-hot pair and the
+    shifted-noise argmax of vis.cost_volume_to_flow (qpwcnet/core/vis.py:22-32)."""
+    a = np.zeros((1, 12, 12, 1), np.float32)
+    b = np.zeros((1, 12, 12, 1), np.float32)
+    a[0, 5, 6, 0] = 2.0
+    b[0, 5 + 3, 6 - 2, 0] = 4.0          # b is a moved by (+3 rows, -2 cols)
+    out = tfa_ref.correlation_cost(a, b)
+    expect = np.zeros_like(out)
+    expect[0, 5, 6, (3 + 4) * 9 + (-2 + 4)] = 8.0
+    np.testing.assert_array_equal(out, expect)
+    # constant images: every in-image displacement gives const^2, out-of-image ones 0 (zero padding)
+    c = np.full((1, 10, 10, 4), 0.5, np.float32)
+    out = tfa_ref.correlation_cost(c, c)
+    assert out[0, 5, 5].min() == 0.25 and out[0, 0, 0, 40] == 0.25
+    assert out[0, 0, 0, 0] == 0.0 and out[0, 9, 9, 80] == 0.0
+    rng = np.random.default_rng(6)
+    prv = rng.standard_normal((1, 24, 28, 64)).astype(np.float32)
+    for dy, dx in ((2, -3), (-4, 4)):
+        nxt = np.roll(prv, (dy, dx), axis=(1, 2))
+        k = np.argmax(tfa_ref.cost_volume_v2(prv, nxt), axis=-1)[0, 8:16, 8:20]
+        assert np.all(k == (dy + 4) * 9 + (dx + 4))
