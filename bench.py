@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Headline benchmark: image-pairs/sec of full 6-level PWC-Net (qpwcnet ``build_flower``)
-inference at 256x512 fp32, batch 8 per GPU (BASELINE.json configs[1]; configs[2] = the same
-per-GPU work on 8 GPUs), synthetic frames and seeded random-init weights.
+inference, synthetic frames and seeded random-init weights.  Default workload = BASELINE.json
+configs[1] (batch 8 per GPU, 256x512 fp32; configs[2] = the same per-GPU work on 8 GPUs).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one forward pass of one batch already resident in HBM: encoder/decoder/flow
-estimator convolutions on PyTorch-ROCm, 5 cost volumes + 4 warps in the HIP kernels,
-6 per-level EPE reductions, and (N > 1) one RCCL all-gather of the 6-float EPE vector.
-Prints ONE JSON line on rank 0.
+A step = one forward pass of one batch already resident in HBM: encoder / decoder / flow estimator and
+the hot path (5 cost volumes + 4 warps) in the HIP kernels, the wide coarse-level pointwise GEMMs on
+rocBLAS, 6 per-level EPE reductions, and (N > 1) one RCCL all-gather of the 6-float EPE vector.
+Prints ONE JSON line on rank 0.  On one GPU the line also carries `extra_configs`: BASELINE configs[3]
+(batch 16, 1024x2048 fp32) and configs[4] (batch 32, 256x512 fp16) measured the same way, each with
+its own roofline block -- reported beside the headline, never as `value`.
 """
 import argparse
 import json
@@ -24,14 +26,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from qpwcnet_amd import _hip  # noqa: E402
 from qpwcnet_amd import dist as qdist  # noqa: E402
 from qpwcnet_amd import metrics, ops, synth  # noqa: E402
 from qpwcnet_amd.pwcnet import GraphedForward, build_flower  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s copy-measured
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is what its float4 copy reaches
+HBM_GUIDE_COPY_GBS = 6290.0
+F32_MFMA_PEAK_TFS = 157.3  # dense fp32 matrix peak (same guide)
+F16_MFMA_PEAK_TFS = 2500.0  # dense fp16/bf16 matrix peak
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
@@ -40,20 +46,45 @@ def parse_args():
     p.add_argument("--height", type=int, default=256)
     p.add_argument("--width", type=int, default=512)
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    p.add_argument("--fused", dest="fused", action="store_true", default=False,
-                   help="fused warp+cost-volume UpFlow front end")
+    p.add_argument("--fused", dest="fused", action="store_true", default=None,
+                   help="force the fused warp+cost-volume UpFlow front end at every level")
+    p.add_argument("--no-fused", dest="fused", action="store_false",
+                   help="never fuse warp + cost volume (default: per level, where it is faster)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-overlap", action="store_true",
                    help="decoder and flow chain on one stream (A/B of the two-stream forward)")
     p.add_argument("--inflight", type=int, default=2, help="batches in flight of the serving_throughput leg")
     p.add_argument("--no-inflight", action="store_true",
                    help="skip the extra '2 batches in flight' throughput measurement (N=1 only)")
+    p.add_argument("--no-extra", action="store_true",
+                   help="skip the extra_configs legs (BASELINE configs[3] and configs[4]; N=1 default run only)")
     p.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                    help="f16 = BASELINE configs[4] (fp16 storage / convs, fp32 accumulate in the hot path)")
+    p.add_argument("--data-format", default="channels_last", choices=["channels_last", "channels_first"],
+                   help="layout of the model's inputs and outputs (reference default for inference: "
+                        "channels_first, app/optical_flow/test_infer.py:52)")
     p.add_argument("--dist-backend", default=None,
                    help="rehearsal only: 'gloo' runs N ranks on ONE GPU (EPE gathered through host memory)")
-    p.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the host for cpu_baseline")
-    return p.parse_args()
+    p.add_argument("--cpu-pairs", type=int, default=2, help="pairs per timed CPU pass of the full net")
+    p.add_argument("--cpu-reps", type=int, default=3, help="timed CPU passes of the full net (median reported)")
+    return p.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# labels: derived from what actually runs
+def baseline_config_name(B, hw, dtype, world):
+    if hw == (256, 512) and dtype == "f32" and B == 8:
+        return "BASELINE configs[1]" if world == 1 else (
+            "BASELINE configs[2]" if world == 8 else "BASELINE configs[1] per GPU on {} GPUs".format(world))
+    if hw == (1024, 2048) and dtype == "f32" and B == 16 and world == 1:
+        return "BASELINE configs[3]"
+    if hw == (256, 512) and dtype == "f16" and B == 32 and world == 1:
+        return "BASELINE configs[4]"
+    return "non-BASELINE workload"
+
+
+def metric_name(hw, dtype):
+    return "image-pairs/sec at {}x{} {}".format(hw[0], hw[1], "fp32" if dtype == "f32" else "fp16")
 
 
 def cost_volume_bytes(B, H, W, C, esize=4):
@@ -62,39 +93,424 @@ def cost_volume_bytes(B, H, W, C, esize=4):
     return B * H * W * (2 * C + 81) * esize
 
 
+def warp_bytes(B, H, W, C, esize=4):
+    """B*H*W*(2C+2)*e (flow counted at the element size of the image, as there)."""
+    return B * H * W * (2 * C + 2) * esize
+
+
+def fused_front_bytes(B, H, W, C, esize=4):
+    """SURVEY.md 8(d), fused warp + cost volume: B*H*W*(2C+2+81)*e."""
+    return B * H * W * (2 * C + 2 + 81) * esize
+
+
+def sepconv_flops(B, H, W, C, F):
+    """depthwise 3x3 (18 flop per channel) + pointwise (2F per channel)."""
+    return B * H * W * C * (2 * F + 18)
+
+
+def cost_volume_symbol(B, H, W, C, dtype):
+    """The kernel symbol qpwc_cost_volume_fwd selects for an NHWC r=4 launch -- the same eligibility rule
+    as cost_volume_mfma_launch (csrc/cost_volume_mfma.hip)."""
+    if C % 16:
+        return "cost_volume_tiled_kernel"
+    regions = ((W + 7) // 8) * ((H + 7) // 8) * B
+    if C % 32 == 0 and regions >= 256:
+        return "cost_volume_mfma_lds_kernel" if dtype == "f32" else "cost_volume_mfma_lds_f16_kernel"
+    return "cost_volume_mfma_kernel"
+
+
+# ---------------------------------------------------------------------------------------------
+# timing helpers (HIP events on the stream the kernels are launched on = torch's current stream)
 def device_copy_ceiling(dev, mib=512, reps=10):
-    """GB/s (read + write bytes) of a dense device-to-device copy: the achievable HBM ceiling of this
-    box that SURVEY 8(d) asks to report beside the 8 TB/s nominal peak."""
-    src = torch.empty(mib << 20, dtype=torch.uint8, device=dev).random_(0, 255)
+    """GB/s (read + write bytes) of the library's own float4 copy kernel (qpwc_device_copy, 16 B per
+    lane): the achievable HBM ceiling of THIS box that SURVEY 8(d) asks to report beside the 8 TB/s
+    nominal peak (the guide's float4 copy: 6.29 TB/s)."""
+    n = mib << 20
+    src = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
     dst = torch.empty_like(src)
-    for _ in range(2):
-        dst.copy_(src)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    e1.record()
-    e1.synchronize()
-    return 2.0 * src.numel() * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    L = _hip.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        _hip.check(L.qpwc_device_copy(src.data_ptr(), dst.data_ptr(), n, st))
+
+    for _ in range(3):
+        run()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    assert torch.equal(dst[:4096], src[:4096]) and torch.equal(dst[-4096:], src[-4096:])
+    return 2.0 * n * reps / (sorted(ts)[1] * 1e-3) / 1e9
 
 
-def cpu_baseline(weights, pairs_np, n_pairs, gpu_flows):
-    """The reference-algorithm CPU restatement (oracle/net_ref.py; TF2 itself cannot run
-    offline) on the host cores, on the first n_pairs of the same workload."""
+def replay_launches(fn, n_rep=50, rounds=5):
+    """Average duration of `fn`'s launch: n_rep back-to-back launches captured in one hipGraph and
+    replayed between two HIP events (no host launch gaps, whatever the host's speed); median round."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    try:
+        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                for _ in range(n_rep):
+                    fn()
+        run = g.replay
+    except RuntimeError:   # capture refused (e.g. by another library's stream activity): eager replays
+        def run():
+            for _ in range(n_rep):
+                fn()
+    run()   # one untimed replay: clocks and caches in their steady state
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) / n_rep)
+    return sorted(ts)[len(ts) // 2]   # median round, not the best one
+
+
+def load_traffic(key):
+    """HBM bytes per launch from profiles/traffic.json (separate rocprofv3 --pmc passes,
+    tools/make_traffic.sh) -- only when the kernel sources still hash to what was profiled."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/traffic.json missing"
+    try:
+        t = json.load(open(tpath))
+    except Exception as e:  # noqa: BLE001
+        return None, "unreadable: {}".format(e)
+    if t.get("kernel_source_sha256") != _hip.source_sha256():
+        return None, "stale: kernel sources changed since the counters were read (tools/make_traffic.sh)"
+    return t.get(key), "profiles/traffic.json ({})".format(t.get("tag", "untagged"))
+
+
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(weights, pairs_np, n_pairs, reps, gpu_flows, hw):
+    """The reference-algorithm CPU restatement (TF2 itself cannot run offline) on the host cores:
+    the two hot-path ops op for op (oracle/torch_ref.py: 81 x slice*mul*mean + concat + lrelu; gather
+    warp) at their L4 shape as MEDIAN of 10, and the full 6-level net (oracle/net_ref.py) on n_pairs
+    pairs of the same batch as MEDIAN of `reps` after one warm-up."""
     from oracle import net_ref, torch_ref
+    cores = torch.get_num_threads()
     n_pairs = max(1, min(n_pairs, pairs_np.shape[0]))
     net = net_ref.RefNet(weights)
-    cores = torch.get_num_threads()
-    net(pairs_np[:1])  # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    ref = net(pairs_np[:n_pairs])
-    dt = time.perf_counter() - t0
+    t_all = time.perf_counter()
+    ref = net(pairs_np[:n_pairs])  # warm-up (thread pool, allocator) -- also the parity reference
+    ts = []
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        net(pairs_np[:n_pairs])
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
     epe = [float(torch_ref.epe_error(a[:n_pairs].float().cpu(), b)) for a, b in zip(gpu_flows, ref)]
+    # hot-path ops alone, one pair at the finest level shape
+    g = torch.Generator().manual_seed(0)
+    shp = (1, hw[0] // 2, hw[1] // 2, synth.level_channels()[-1])
+    prv, nxt = torch.randn(shp, generator=g), torch.randn(shp, generator=g)
+    flo = torch.randn(shp[:3] + (2,), generator=g) * 4
+
+    def med(fn, n=10):
+        fn()
+        out = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            out.append(time.perf_counter() - t0)
+        return sorted(out)[n // 2]
+    t_cv = med(lambda: torch_ref.cost_volume(prv, nxt))
+    t_wp = med(lambda: torch_ref.warp_v2(nxt, flo))
+    total = time.perf_counter() - t_all
     return {
         "value": n_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-        "sample": "{} pairs of the same batch, full 6-level net, torch-CPU op-for-op restatement "
-                  "(81x slice*mul*mean cost volume, gather warp), {:.1f} s".format(n_pairs, dt),
+        "sample": "{} pairs of the same batch, full 6-level net, torch-CPU op-for-op restatement (81x "
+                  "slice*mul*mean cost volume, gather warp): median of {} passes of {:.1f} s after one "
+                  "warm-up; whole cpu_baseline leg {:.0f} s".format(n_pairs, len(ts), dt, total),
+        "net_pass_s": [round(t, 3) for t in ts],
+        "hot_path_ops": {
+            "shape": "x".join(map(str, shp)), "runs": 10, "statistic": "median",
+            "cost_volume_ms": 1e3 * t_cv, "cost_volume_GBs": cost_volume_bytes(*shp) / t_cv / 1e9,
+            "warp_v2_ms": 1e3 * t_wp, "warp_v2_GBs": warp_bytes(*shp) / t_wp / 1e9,
+        },
     }, epe
+
+
+# ---------------------------------------------------------------------------------------------
+def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
+    """Live roofline blocks of one configuration: the L4 cost-volume launch (dominant hot-path kernel,
+    HBM), the L4 WarpV2 (HBM), the fused UpFlow front end where the model uses it (HBM), and the first
+    fused SeparableConv2D of L4 (the step's largest kernel; fp32 matrix pipe)."""
+    esize = 4 if dtype == "f32" else 2
+    chans = synth.level_channels()
+    lvl4 = (B, hw[0] // 2, hw[1] // 2, chans[-1])
+    model.overlap_streams = False   # one stream: events would otherwise time kernels sharing the chip
+    n_prof = 5
+
+    def forward():
+        with torch.no_grad():
+            return model(model_input)
+    key_cv = ("cost_volume",) + lvl4
+    key_fcv = ("warp_cost_volume",) + lvl4
+    with ops.kernel_timing() as kt:
+        for _ in range(n_prof):
+            forward()
+    ktimes = kt.summary()
+    model.overlap_streams = not args.no_overlap
+    out = {}
+    up4 = model.upflows[-1]
+    g = torch.Generator(device=dev).manual_seed(7)
+    prv = torch.randn(lvl4, device=dev, generator=g).to(tdtype)
+    nxt = torch.randn(lvl4, device=dev, generator=g).to(tdtype)
+    flo = torch.randn(lvl4[:3] + (2,), device=dev, generator=g) * 4
+    stride = 84 if up4.flow.wants_cost84(prv) else 81
+    cbuf = torch.empty(lvl4[:3] + (stride,), dtype=tdtype, device=dev)
+
+    def hbm_block(name, symbol, nbytes, ms, traffic_key, extra=None):
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        traffic, tsrc = load_traffic(traffic_key) if dtype == "f32" and lvl4[0] == 8 else (None, "not profiled for this shape")
+        d = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+             "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
+             "frac_of_guide_copy_6290": achieved / HBM_GUIDE_COPY_GBS,
+             "kernel": name, "kernel_symbol": symbol, "algorithmic_bytes_per_launch": nbytes,
+             "avg_launch_ms": ms}
+        d.update(extra or {})
+        return d
+
+    # -- cost volume L4: the step's own launch shape (84-float pixels where the fused first OptFlow layer
+    # reads them), random inputs, 50 back-to-back launches per round
+    fused4 = bool(getattr(up4, "fused", False))
+    cv_ms = replay_launches(lambda: ops.cost_volume_into(prv, nxt, cbuf, 0))
+    sym_by_level = {"L4": cv_ms}
+    for lv in (3, 2, 1, 0):
+        shp = (B, hw[0] >> (5 - lv), hw[1] >> (5 - lv), chans[lv])
+        if cost_volume_symbol(*shp, dtype) != cost_volume_symbol(*lvl4, dtype):
+            break
+        pl = torch.randn(shp, device=dev, generator=g).to(tdtype)
+        nl = torch.randn(shp, device=dev, generator=g).to(tdtype)
+        blk = model.flow if lv == 0 else model.upflows[lv - 1]
+        bl = torch.empty(shp[:3] + (84 if blk.flow.wants_cost84(pl) else 81,), dtype=tdtype, device=dev)
+        sym_by_level["L%d" % lv] = replay_launches(lambda: ops.cost_volume_into(pl, nl, bl, 0))
+    in_step = ktimes.get(key_cv)
+    out["cost_volume"] = hbm_block(
+        "cost_volume L4 {}".format("x".join(map(str, lvl4))), cost_volume_symbol(*lvl4, dtype),
+        cost_volume_bytes(*lvl4, esize), cv_ms, "cost_volume_L4_bytes_per_launch",
+        {"symbol_launch_ms_by_level": sym_by_level,
+         "symbol_avg_ms": sum(sym_by_level.values()) / len(sym_by_level),
+         "avg_launch_ms_inside_eager_step": in_step[1] if in_step else None,
+         "launches_per_step": in_step[0] // n_prof if in_step else 0,
+         "out_pixel_stride": stride,
+         "method": "HIP events on the launch stream around a hipGraph of 50 back-to-back launches at the "
+                   "step's own L4 shape and output pixel stride (84 = 81 channels + 3 zeroed pads; the "
+                   "algorithmic bytes count 81), median of 5 rounds after a warm one"})
+    # -- WarpV2 L4
+    w_ms = replay_launches(lambda: ops.warp(nxt, flo, "clamp"))
+    in_step = ktimes.get(("warp_clamp",) + lvl4)
+    out["warp_v2"] = hbm_block(
+        "WarpV2 L4 {}".format("x".join(map(str, lvl4))), "warp_nhwc_vec4_kernel", warp_bytes(*lvl4, esize),
+        w_ms, "warp_clamp_L4_bytes_per_launch",
+        {"avg_launch_ms_inside_eager_step": in_step[1] if in_step else None,
+         "launches_per_step": in_step[0] // n_prof if in_step else 0})
+    # -- fused WarpV2 + cost volume (SURVEY 8(f) rank 1), scored against the UNFUSED algorithmic bytes and
+    # against its own fused bytes, as SURVEY 8(d) prescribes
+    try:
+        f_ms = replay_launches(lambda: ops.cost_volume_into(prv, nxt, cbuf, 0, flo=flo))
+        unf = cost_volume_bytes(*lvl4, esize) + warp_bytes(*lvl4, esize)
+        fb = fused_front_bytes(*lvl4, esize)
+        in_step = ktimes.get(key_fcv)
+        out["warp_cost_volume_fused"] = hbm_block(
+            "fused WarpV2+cost volume L4 {}".format("x".join(map(str, lvl4))), "warp_cost_volume (see DESIGN 4.9)",
+            fb, f_ms, "warp_cost_volume_L4_bytes_per_launch",
+            {"used_by_the_step_at_L4": fused4, "unfused_pair_ms": cv_ms + w_ms,
+             "unfused_algorithmic_bytes": unf, "achieved_vs_unfused_bytes_GBs": unf / (f_ms * 1e-3) / 1e9,
+             "frac_vs_unfused_bytes": unf / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "avg_launch_ms_inside_eager_step": in_step[1] if in_step else None})
+    except (ValueError, RuntimeError) as e:
+        out["warp_cost_volume_fused"] = {"error": str(e).splitlines()[0]}
+    # -- first SeparableConv2D of L4's OptFlow: [cost | prv | flo] -> 128, fused depthwise + pointwise
+    try:
+        of = up4.flow
+        of._prepare_hip()
+        F_ = of.filters[0]
+        cost = torch.randn(lvl4[:3] + (stride,), device=dev, generator=g).to(tdtype)
+        if stride == 84:
+            cost[..., 81:] = 0
+            dw, pw = of._dw84, (of._pw_pad84 if dtype == "f32" else of._pw_pad84_16)
+        else:
+            dw, pw = of._dw[0], (of._pw_pad[0] if dtype == "f32" else of._pw_pad16[0])
+        srcs = [cost, prv, flo.to(tdtype)]
+        s_ms = replay_launches(lambda: ops.sepconv3x3(srcs, dw, pw, of._pw_b32[0], mish_on_store=True), n_rep=20)
+        c_real = 81 + lvl4[3] + 2
+        fl = sepconv_flops(lvl4[0], lvl4[1], lvl4[2], c_real, F_)
+        peak = F32_MFMA_PEAK_TFS if dtype == "f32" else F16_MFMA_PEAK_TFS
+        tf = fl / (s_ms * 1e-3) / 1e12
+        key_s = [k for k in ktimes if k[0].startswith("sepconv3x3") and k[1:4] == lvl4[:3] and k[-1] == F_]
+        out["sepconv3x3_fused_L4_first_layer"] = {
+            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+            "kernel": "SeparableConv2D {}->{} L4 {}x{}x{}".format(c_real, F_, *lvl4[:3]),
+            "kernel_symbol": "sepconv3x3_fused_kernel<{}>".format(F_) if dtype == "f32"
+                             else "sepconv3x3_fused_f16_kernel<{}>".format(F_),
+            "algorithmic_flops_per_launch": fl, "avg_launch_ms": s_ms,
+            "algorithmic_bytes_per_launch": lvl4[0] * lvl4[1] * lvl4[2] * (c_real + F_) * esize,
+            "avg_launch_ms_inside_eager_step": ktimes[key_s[0]][1] if key_s else None,
+            "note": "the step's largest single kernel; flops = B*H*W*C*(2F+18) with the 115 real input "
+                    "channels (DESIGN.md 4.6), peak = dense {} MFMA".format("fp32" if dtype == "f32" else "fp16")}
+    except (ValueError, RuntimeError, AttributeError) as e:
+        out["sepconv3x3_fused_L4_first_layer"] = {"error": str(e).splitlines()[0]}
+    hot_ms = sum(n * t for k, (n, t) in ktimes.items()
+                 if k[0] in ("cost_volume", "warp_clamp", "warp_cost_volume")) / n_prof
+    hot = {"ms_per_step_eager_events": hot_ms,
+           "kernels_ms": {"{} {}".format(k[0], "x".join(map(str, k[1:]))): round(t, 5)
+                          for k, (n, t) in sorted(ktimes.items())}}
+    return out, hot
+
+
+def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_gbs):
+    """One configuration end to end -> the fields of its JSON object."""
+    tdtype = torch.float32 if dtype == "f32" else torch.float16
+    weights = synth.make_weights(42, hw)
+    cl = args.data_format == "channels_last"
+    model = build_flower(True, hw, args.data_format, weights=weights, device=dev, fused=args.fused,
+                         dtype=tdtype)
+    if args.no_overlap:
+        model.overlap_streams = False
+    pairs_np, gt_np = synth.make_frames(B, hw[0], hw[1], seed=1234 + rank)
+    pairs_cl = torch.from_numpy(pairs_np).to(dev, tdtype)
+    pairs = pairs_cl if cl else pairs_cl.permute(0, 3, 1, 2).contiguous()
+    gt = torch.from_numpy(gt_np).to(dev)
+    shapes = [(hw[0] >> s, hw[1] >> s) for s in (5, 4, 3, 2, 1, 0)]
+    gt_pyr = metrics.multiscale_ground_truth(gt, shapes)
+
+    def epe_of(flows, out=None):
+        if not cl:   # the EPE reduction takes channels-last flows (2 channels: a cheap view-copy)
+            flows = [f.permute(0, 2, 3, 1) for f in flows]
+        return metrics.per_level_epe(gt_pyr, flows, out=out)
+
+    def forward():
+        with torch.no_grad():
+            flows = model(pairs)
+            return flows, epe_of(flows)
+
+    # eager warm-up (library solver search, LDS attribute set-up) before any capture
+    for _ in range(3):
+        flows, epe_local = forward()
+    torch.cuda.synchronize()
+
+    # The one collective of the path: an all-gather of the 6 per-level EPE (+ shard weight) per step.
+    # On RCCL it is asynchronous: the exchange of step k travels while step k+1 computes, and its result
+    # is consumed (the stream waits for it) one step later; the last one is drained inside the timed region.
+    # (CPU rehearsal of the N > 1 path, --dist-backend gloo: the same submit/collect pattern on host tensors)
+    gloo = args.dist_backend == "gloo"
+    gather = qdist.EpeGather(6, "cpu" if gloo else dev, n_local=B)
+    in_place = gather.collective and not gloo   # the graphs' EPE reductions write the payload themselves
+
+    graphs = None
+    if not args.no_graph:
+        try:
+            if in_place:
+                # two graphs over ONE memory pool, replayed alternately: they differ only in the payload
+                # slot the captured EPE reduction writes, so no copy stands between it and the collective
+                g0 = GraphedForward(model, pairs, epilogue=lambda fl: epe_of(fl, gather.payload_view(0)), warmup=0)
+                g1 = GraphedForward(model, pairs, epilogue=lambda fl: epe_of(fl, gather.payload_view(1)), warmup=0,
+                                    share_with=g0)
+                graphs = [g0, g1]
+            else:
+                graphs = [GraphedForward(model, pairs, epilogue=epe_of, warmup=0)]
+            flows, epe_local = graphs[0].outputs, graphs[0].extra
+        except RuntimeError as e:   # capture refused: keep measuring, with eager launches
+            print("bench.py: hipGraph capture failed ({}); eager launches".format(str(e).splitlines()[0]),
+                  file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
+
+    def run_step(k):
+        if graphs is not None and in_place:
+            s = gather.next_slot()
+            graphs[s].replay()
+            return s
+        if graphs is not None:
+            graphs[0].replay()
+            e = graphs[0].extra
+        else:
+            _, e = forward()
+        return e.cpu() if gloo else e
+
+    elapsed, results = qdist.timed_steps(run_step, gather, steps, warmup, dev)
+    per_rank, epe_mean = results[-1]
+    assert len(results) == steps
+
+    res = {
+        "metric": metric_name(hw, dtype),
+        "value": world * B * steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
+        "config": {
+            "workload": "{}: full 6-level PWC-Net (qpwcnet build_flower) inference, batch {} per GPU, "
+                        "{}x{} {}, {}, d=4 cost volume + WarpV2".format(
+                            baseline_config_name(B, hw, dtype, world), B, hw[0], hw[1],
+                            "fp32" if dtype == "f32" else "fp16 storage (fp32 accumulate)", args.data_format),
+            "global_batch": world * B, "batch_per_gpu": B,
+            "parallelism": "dp{} (pairs sharded, RCCL all-gather of the 6 per-level EPE)".format(world),
+            "hipgraph": graphs is not None,
+            "epe_payload": ("written by the captured EPE reduction (two graphs, one pool)" if graphs is not None
+                            and in_place else ("copied per step" if gather.collective else "single process")),
+            "fused_upflow": [bool(u.fused) for u in model.upflows],
+            "hip_optflow": True,
+            "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",
+        },
+        "per_level_epe_vs_ground_truth": [float(x) for x in epe_mean.cpu()],
+    }
+
+    # ---- serving-style throughput, reported BESIDE the headline (never as `value`): two batches
+    # in flight, each a hipGraph replay on its own stream, so that the launch-bound coarse levels of
+    # one batch run under the encoder / finest level of the other.  Same K steps, same work per step.
+    if headline and graphs is not None and world == 1 and not args.no_inflight:
+        n_fly = max(2, args.inflight)
+        lanes = [(torch.cuda.Stream(), graphs[0])]
+        for k in range(1, n_fly):
+            pk, _ = synth.make_frames(B, hw[0], hw[1], seed=4321 + k)
+            pk = torch.from_numpy(pk).to(dev, tdtype)
+            lanes.append((torch.cuda.Stream(),
+                          GraphedForward(model, pk if cl else pk.permute(0, 3, 1, 2).contiguous(),
+                                         epilogue=epe_of, warmup=0)))
+        torch.cuda.synchronize()
+
+        def run(n):
+            for i in range(n):
+                st, g = lanes[i % n_fly]
+                with torch.cuda.stream(st):
+                    g.replay()
+
+        run(max(n_fly, warmup))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        res["serving_throughput"] = {
+            "batches_in_flight": n_fly, "value": B * steps / dt, "unit": "pairs/s",
+            "ms_per_step": dt / steps * 1e3,
+            "note": "{} hipGraph replays (batch {} each) on as many streams; not the headline value".format(n_fly, B)}
+        del lanes[1:]
+
+    # ---- live rooflines (single stream, HIP events)
+    blocks, hot = rooflines(model, pairs, B, hw, dtype, tdtype, dev, args, copy_gbs)
+    res["roofline"] = blocks.pop("cost_volume")
+    res["rooflines_other"] = blocks
+    res["hot_path"] = hot
+    return res, (weights, pairs_np, flows)
 
 
 def main():
@@ -112,249 +528,39 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode: pick the fastest conv solver once
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode (fp16 library convolutions): fastest solver once
 
-    hw = (args.height, args.width)
-    B = args.batch
-    weights = synth.make_weights(42, hw)
-    tdtype = torch.float32 if args.dtype == "f32" else torch.float16
-    esize = 4 if args.dtype == "f32" else 2
-    model = build_flower(True, hw, "channels_last", weights=weights, device=dev, fused=args.fused,
-                         dtype=tdtype)
-    if args.no_overlap:
-        model.overlap_streams = False
-    pairs_np, gt_np = synth.make_frames(B, hw[0], hw[1], seed=1234 + rank)
-    pairs = torch.from_numpy(pairs_np).to(dev, tdtype)
-    gt = torch.from_numpy(gt_np).to(dev)
-    shapes = [(hw[0] >> s, hw[1] >> s) for s in (5, 4, 3, 2, 1, 0)]
-    gt_pyr = metrics.multiscale_ground_truth(gt, shapes)
-
-    def forward():
-        with torch.no_grad():
-            flows = model(pairs)
-            return flows, metrics.per_level_epe(gt_pyr, flows)
-
-    # eager warm-up (MIOpen solver search, LDS attribute set-up) before any capture
-    for _ in range(3):
-        flows, epe_local = forward()
-    torch.cuda.synchronize()
-
-    graph = None
-    if not args.no_graph:
-        try:
-            graph = GraphedForward(model, pairs, epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=0)
-            flows, epe_local = graph.outputs, graph.extra
-        except RuntimeError as e:   # capture refused: keep measuring, with eager launches
-            print("bench.py: hipGraph capture failed ({}); eager launches".format(str(e).splitlines()[0]),
-                  file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    # The one collective of the path: an all-gather of the 6 per-level EPE (+ shard weight) per step.
-    # On RCCL it is asynchronous: the exchange of step k travels while step k+1 computes, and its result
-    # is consumed (the stream waits for it) one step later; the last one is drained inside the timed region.
-    # (CPU rehearsal of the N > 1 path, --dist-backend gloo: the same submit/collect pattern on host tensors)
-    gloo = args.dist_backend == "gloo"
-    gather = qdist.EpeGather(6, "cpu" if gloo else dev, n_local=B)
-
-    def step():
-        if graph is not None:
-            graph.replay()
-            e = epe_local
-        else:
-            _, e = forward()
-        gather.submit(e.cpu() if gloo else e)
-        return gather.collect() if gather.outstanding() > 1 else None
-
-    def drain():
-        out = None
-        while gather.outstanding():
-            out = gather.collect()
-        return out
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    qdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
-        res = step() or res
-    res = drain() or res
-    qdist.barrier()
-    torch.cuda.synchronize()
-    elapsed = qdist.max_over_ranks(time.perf_counter() - t0, dev)
-    per_rank, epe_mean = res
-
-    # ---- serving-style throughput, reported BESIDE the headline (never as `value`): two batches of 8
-    # in flight, each a hipGraph replay on its own stream, so that the launch-bound coarse levels of
-    # one batch run under the encoder / finest level of the other.  Same K steps, same work per step.
-    serving = None
-    if graph is not None and world == 1 and not args.no_inflight:
-        n_fly = max(2, args.inflight)
-        lanes = [(torch.cuda.Stream(), graph)]
-        for k in range(1, n_fly):
-            pk, _ = synth.make_frames(B, hw[0], hw[1], seed=4321 + k)
-            lanes.append((torch.cuda.Stream(), GraphedForward(model, torch.from_numpy(pk).to(dev, tdtype),
-                                                              epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl),
-                                                              warmup=0)))
-        torch.cuda.synchronize()
-
-        def run(n):
-            for i in range(n):
-                st, g = lanes[i % n_fly]
-                with torch.cuda.stream(st):
-                    g.replay()
-
-        run(max(n_fly, args.warmup))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run(args.steps)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        serving = {"batches_in_flight": n_fly, "value": B * args.steps / dt, "unit": "pairs/s",
-                   "ms_per_step": dt / args.steps * 1e3,
-                   "note": "{} hipGraph replays (batch {} each) on as many streams; not the headline value".format(
-                       n_fly, B)}
-        del lanes[1:]
-
-    # ---- live roofline of the dominant hot-path kernel: HIP events on the launch stream
-    # (single stream for this pass: with the decoder running beside it on the side stream the
-    # events would time the kernel while it shares the chip)
+    info = _hip.build_info()
     copy_gbs = device_copy_ceiling(dev)
-    n_prof = max(5, min(args.steps, 20))
-    lvl4 = (B, hw[0] // 2, hw[1] // 2, synth.level_channels()[-1])
-    dom_name = "warp_cost_volume" if args.fused else "cost_volume"
-    dom_key = (dom_name,) + lvl4
-    model.overlap_streams = False
-    lvl3 = (B, hw[0] // 4, hw[1] // 4, synth.level_channels()[-2])
-    with ops.kernel_timing(capture=dom_key) as kt:
-        for _ in range(n_prof):
-            forward()
-    ktimes = kt.summary()
-    model.overlap_streams = not args.no_overlap
-    _, dom_ms_eager = ktimes[dom_key]
-    dom_ms = dom_ms_eager
-    def replay_launches(fn, n_rep=50):
-        """Average duration of `fn`'s launch: n_rep back-to-back launches captured in one hipGraph and
-        replayed between two HIP events (no host launch gaps, whatever the host's speed)."""
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        try:
-            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    for _ in range(n_rep):
-                        fn()
-            run = g.replay
-        except RuntimeError:   # capture refused (e.g. by another library's stream activity): eager replays
-            def run():
-                for _ in range(n_rep):
-                    fn()
-        run()   # one untimed replay: clocks and caches in their steady state
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            run()
-            e1.record()
-            e1.synchronize()
-            ts.append(e0.elapsed_time(e1) / n_rep)
-        return sorted(ts)[len(ts) // 2]   # median round, not the best one
-
-    if kt.captured is not None:
-        # The eager pass times event -> (host launch latency) -> kernel -> event.  For the launch
-        # DURATION rocprofv3 reports, replay the step's own launch (same inputs, same output pixel stride)
-        # back to back: the queue never drains, so (t1 - t0) / n is the kernel time.
-        cp, cn, cstride = kt.captured
-        cbuf = torch.empty(cp.shape[:3] + (cstride,), dtype=cp.dtype, device=cp.device)
-        dom_ms = replay_launches(lambda: ops.cost_volume_into(cp, cn, cbuf, 0))
-    dom_bytes = cost_volume_bytes(*lvl4, esize)
-    # The same kernel symbol also serves the coarser levels that give it >= 256 regions of 8x8 pixels (L2
-    # and L3 at B=8, 256x512; one launch per step each): time those launches the same way, so that the
-    # per-level figures compare with rocprofv3's per-grid durations and their mean with its per-symbol
-    # AverageNs.
-    sym_avg_ms, sym_by_level = None, None
-    if kt.captured is not None and not args.fused:
-        sym_by_level = {"L4": dom_ms}
-        chans = synth.level_channels()
-        for lv in (3, 2, 1, 0):
-            shp = (B, hw[0] >> (5 - lv), hw[1] >> (5 - lv), chans[lv])
-            regions = B * ((shp[1] + 7) // 8) * ((shp[2] + 7) // 8)
-            if shp[3] % 32 or regions < 256:
-                break
-            pl = torch.randn(shp, device=dev, dtype=tdtype)
-            nl = torch.randn(shp, device=dev, dtype=tdtype)
-            # the step writes 84-channel pixels where the first OptFlow layer is fused, dense 81 elsewhere
-            blk = model.flow if lv == 0 else model.upflows[lv - 1]
-            stride = kt.captured[2] if blk.flow.wants_cost84(pl) else 81
-            bl = torch.empty(shp[:3] + (stride,), dtype=tdtype, device=dev)
-            sym_by_level["L%d" % lv] = replay_launches(lambda: ops.cost_volume_into(pl, nl, bl, 0))
-        sym_avg_ms = sum(sym_by_level.values()) / len(sym_by_level)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from a separate rocprofv3 --pmc run
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom_name + "_L4_bytes_per_launch")
-        except Exception:
-            traffic = None
-    hot_ms = sum(n * t for (n, t) in ktimes.values()) / n_prof
-
-    result = {
-        "metric": "image-pairs/sec at 256x512 fp32",
-        "value": world * B * args.steps / elapsed,
-        "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {
-            "workload": "BASELINE configs[1]: full 6-level PWC-Net (qpwcnet build_flower) inference, "
-                        "batch {} per GPU, {}x{} {}, d=4 cost volume + WarpV2".format(
-                            B, hw[0], hw[1], "fp32" if args.dtype == "f32" else "fp16"),
-            "global_batch": world * B, "batch_per_gpu": B,
-            "parallelism": "dp{} (pairs sharded, RCCL all-gather of the 6 per-level EPE)".format(world),
-            "hipgraph": graph is not None, "fused_upflow": bool(args.fused),
-            "hip_optflow": True,
-            "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",
-        },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            # SURVEY 8(d): the ceiling a plain device copy reaches on this box, measured now
-            "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
-            "kernel": "{} L4 {}".format(dom_name, "x".join(map(str, lvl4))),
-            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-            "avg_launch_ms_inside_eager_step": dom_ms_eager,
-            "kernel_symbol": "cost_volume_mfma_lds_kernel" if args.dtype == "f32" else "cost_volume_mfma_lds_f16_kernel",
-            # compare with rocprofv3: per-grid durations of the symbol / its --stats AverageNs
-            "symbol_launch_ms_by_level": sym_by_level, "symbol_avg_ms": sym_avg_ms,
-            "launches_timed": ktimes[dom_key][0],
-            "out_pixel_stride": kt.captured[2] if kt.captured is not None else None,
-            "method": "HIP events on the launch stream around a hipGraph of 50 back-to-back replays of the "
-                      "step's own L4 launch (inputs and output pixel stride captured from the forward; "
-                      "stride 84 = 81 channels + 3 zeroed pads, the algorithmic bytes count 81); the "
-                      "eager-step figure also contains the host launch gap",
-        },
-        "hot_path": {
-            "ms_per_step_eager_events": hot_ms,
-            "kernels_ms": {"{} {}".format(k[0], "x".join(map(str, k[1:]))): round(t, 5)
-                           for k, (n, t) in sorted(ktimes.items())},
-        },
-        "per_level_epe_vs_ground_truth": [float(x) for x in epe_mean.cpu()],
-        "serving_throughput": serving,
-    }
+    hw = (args.height, args.width)
+    result, (weights, pairs_np, flows) = measure(args, args.batch, hw, args.dtype, args.steps, args.warmup,
+                                                 world, rank, dev, True, copy_gbs)
+    result["library"] = info
+    default_run = (world == 1 and args.batch == 8 and hw == (256, 512) and args.dtype == "f32" and
+                   args.data_format == "channels_last" and not args.no_graph)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            base, epe_oracle = cpu_baseline(weights, pairs_np, args.cpu_pairs, flows)
+            base, epe_oracle = cpu_baseline(weights, pairs_np, args.cpu_pairs, args.cpu_reps, flows, hw)
             result["cpu_baseline"] = base
             result["per_level_epe_vs_oracle"] = epe_oracle
         else:
             result["cpu_baseline"] = None
+    del flows
+    if default_run and not args.no_extra:
+        # BASELINE configs[3] and configs[4] on the driver's clock too: same procedure, fewer steps
+        # (config 3 is ~25 ms per step), their own roofline blocks; never the headline `value`
+        extra = []
+        for (b, h, w, dt, st, wu) in ((16, 1024, 2048, "f32", 10, 3), (32, 256, 512, "f16", 30, 5)):
+            torch.cuda.empty_cache()
+            try:
+                r, keep = measure(args, b, (h, w), dt, st, wu, world, rank, dev, False, copy_gbs)
+                del keep
+                extra.append(r)
+            except (RuntimeError, ValueError) as e:  # report, do not lose the headline line
+                extra.append({"metric": metric_name((h, w), dt), "error": str(e).splitlines()[0],
+                              "config": {"workload": baseline_config_name(b, (h, w), dt, world)}})
+        result["extra_configs"] = extra
+    if rank == 0:
         print(json.dumps(result))
     if world > 1:
         qdist.barrier()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define QPWC_VERSION 100 /* 0.1.0 */
+#define QPWC_VERSION 200 /* 0.2.0 */
 
 /* layout of every image-like tensor of one call */
 #define QPWC_NHWC 0 /* 'channels_last'  (B,H,W,C) */
@@ -59,6 +59,15 @@ extern "C" {
 int qpwc_version(void);
 const char* qpwc_last_error(void);
 const char* qpwc_strerror(int code);
+/* Static description of the build.  The product library selects kernels from the call's arguments
+ * only (no environment variable changes what runs); the `make experimental` build of the same ABI
+ * keeps A/B switches and reports "EXPERIMENTAL" here. */
+const char* qpwc_build_info(void);
+
+/* Measurement aid ("measure the achievable ceiling on the box with a device copy
+ * kernel"): dst[0..bytes) = src[0..bytes), 16 B per lane, bytes % 16 == 0, both 16-byte aligned.
+ * Not part of the reference's surface. */
+int qpwc_device_copy(const void* src, void* dst, int64_t bytes, void* stream);
 
 /* CostVolume / CostVolumeV2 forward.
  * Replaces: CostVolume.call           qpwcnet/core/layers.py:72-100

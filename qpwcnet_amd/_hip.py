@@ -22,7 +22,7 @@ _ARGUMENT_ERRORS = {E_NULL, E_LAYOUT, E_DTYPE, E_SHAPE, E_RANGE, E_MODE, E_ALIAS
 
 # every symbol include/qpwc.h declares
 SYMBOLS = (
-    "qpwc_version", "qpwc_last_error", "qpwc_strerror",
+    "qpwc_version", "qpwc_last_error", "qpwc_strerror", "qpwc_build_info", "qpwc_device_copy",
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_bias_mish_fwd",
@@ -70,6 +70,10 @@ def lib():
     L.qpwc_last_error.restype = ctypes.c_char_p
     L.qpwc_strerror.argtypes = [ci]
     L.qpwc_strerror.restype = ctypes.c_char_p
+    L.qpwc_build_info.argtypes = []
+    L.qpwc_build_info.restype = ctypes.c_char_p
+    L.qpwc_device_copy.argtypes = [vp, vp, i64, vp]
+    L.qpwc_device_copy.restype = ci
     L.qpwc_cost_volume_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp]
     L.qpwc_cost_volume_fwd.restype = ci
     L.qpwc_cost_volume_fwd_strided.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, i64, i64, vp]
@@ -124,6 +128,26 @@ def lib():
     L.qpwc_upconv4x4s2_mish_fwd.restype = ci
     _lib = L
     return L
+
+
+def build_info():
+    """{'path', 'version', 'build', 'product'} of the loaded library: bench.py prints it, so that a number
+    from another build (QPWC_HIP_LIB -> `make experimental`) can never pass for the product's."""
+    L = lib()
+    info = L.qpwc_build_info().decode()
+    return {"path": LIB_PATH, "version": int(L.qpwc_version()), "build": info,
+            "product": "EXPERIMENTAL" not in info and not os.environ.get("QPWC_HIP_LIB")}
+
+
+def source_sha256(names=("cost_volume_mfma.hip", "cost_volume.hip", "warp.hip", "common.h")):
+    """sha256 over the named kernel sources (qpwcnet_amd/csrc): stamps profiles/traffic.json, and
+    bench.py drops `roofline.traffic` when the kernels have changed since the counters were read."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(_HERE, "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def check(rc):

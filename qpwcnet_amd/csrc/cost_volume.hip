@@ -288,15 +288,6 @@ __global__ __launch_bounds__(256) void zero_pads_kernel(T* __restrict__ out, int
         st(out + (i / 3) * 84 + 81 + (i % 3), 0.0f);
 }
 
-// QPWC_CV_IMPL=valu forces the LDS-tiled vector kernel (A/B measurements only).
-static bool use_mfma() {
-    static const bool v = [] {
-        const char* e = getenv("QPWC_CV_IMPL");
-        return !(e && e[0] == 'v');
-    }();
-    return v;
-}
-
 // pad84: the caller passes ops == 84 with channel offset 0 and wants channels 81..83 zeroed (an
 // 84-channel cost volume whose pixels are 16-byte aligned, for vector loads downstream).
 int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* out, int B, int H,
@@ -310,7 +301,7 @@ int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* 
         else
             hipLaunchKernelGGL(zero_pads_kernel<__half>, dim3(grid), dim3(256), 0, s, (__half*)out, npx);
     };
-    if (!fuse && layout == QPWC_NHWC && r == 4 && use_mfma()) {
+    if (!fuse && layout == QPWC_NHWC && r == 4) {
         bool pads_written = false;
         const int rc = cost_volume_mfma_launch(prv, nxt, out, B, H, W, C, dtype, ops, slope, pad84 ? 1 : 0,
                                                &pads_written, s);

@@ -670,7 +670,10 @@ static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int
 #include "experimental/cost_volume_pipe.inc"
 #endif
 
-// QPWC_CV_LDS=0 keeps every shape on the per-wave split-K kernel (A/B measurements only).
+// The product build reads NO environment variable: every rank of a multi-GPU job runs the same kernels.
+// Only `make experimental` (libqpwc_exp.so, reported by qpwc_build_info()) keeps the A/B switch
+// QPWC_CV_LDS=0 = every shape on the per-wave split-K kernel.
+#ifdef QPWC_EXPERIMENTAL
 static int lds_mode() {
     static const int v = [] {
         const char* e = getenv("QPWC_CV_LDS");
@@ -678,6 +681,9 @@ static int lds_mode() {
     }();
     return v;
 }
+#else
+static constexpr int lds_mode() { return 1; }
+#endif
 
 static int launch_lds(const float* prv, const float* nxt, float* out, int B, int H, int W, int C,
                       int64_t ops, float slope, int pad84, hipStream_t s) {
@@ -782,6 +788,16 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
 }
 
 }  // namespace qpwc
+
+// Which build this is: the product library has no run-time kernel switches; the experimental one does
+// and says so, so that a bench line can never silently come from it.
+extern "C" const char* qpwc_build_info(void) {
+#ifdef QPWC_EXPERIMENTAL
+    return "libqpwc_hip gfx950 EXPERIMENTAL (env switches QPWC_CV_LDS / QPWC_CV_RING / QPWC_CV_PIPE active)";
+#else
+    return "libqpwc_hip gfx950 product (no environment switches)";
+#endif
+}
 
 #if defined(QPWC_EXPERIMENTAL) && defined(QPWC_STAMP)
 #include "experimental/debug_exports.inc"

@@ -71,7 +71,13 @@ class EpeGather:
     ``collect()`` returns the OLDEST outstanding result -- the caller's stream waits for that collective,
     which by then has had a whole step to finish -- as (per_rank [world, L], global_mean [L]).
     Buffers are allocated once; nothing is copied from the host per step.  Single process: no
-    collective, submit/collect are a queue of clones."""
+    collective, submit/collect are a queue of clones.
+
+    Copy-free form (what bench.py's hipGraph steps use): the producer writes its vector straight into
+    ``payload_view(slot)`` in stream order -- the EPE reduction captured inside graph `slot` does -- and
+    calls ``submit(slot=slot)``.  Slots alternate 0, 1, 0, ...: slot s is rewritten by step k+2 only after
+    ``collect()`` of step k made the caller's stream wait for all-gather k, which read it (at most two
+    collectives are ever outstanding, enforced below)."""
 
     def __init__(self, n_levels, device, n_local=1, dtype=torch.float32):
         # a process group of one rank still runs the collective (that is how the RCCL path is tested on
@@ -81,22 +87,37 @@ class EpeGather:
         self.L = int(n_levels)
         self.pending = []
         self.slot = 0
+        w = self.L + 1
+        self.payload = [torch.zeros(w, dtype=dtype, device=device) for _ in range(2)]
+        for p in self.payload:
+            p[-1] = float(n_local)      # shard weight, constant over the run
         if self.collective:
-            w = self.L + 1
-            self.payload = [torch.zeros(w, dtype=dtype, device=device) for _ in range(2)]
-            for p in self.payload:
-                p[-1] = float(n_local)      # shard weight, constant over the run
             self.flat = [torch.empty(self.world * w, dtype=dtype, device=device) for _ in range(2)]
 
-    def submit(self, local_epe):
-        if not self.collective:
-            self.pending.append((None, local_epe.clone()))
-            return
+    def payload_view(self, slot):
+        """The L-float window of payload buffer `slot` (0 or 1) a producer may write in place."""
+        return self.payload[slot][:self.L]
+
+    def next_slot(self):
+        return self.slot
+
+    def submit(self, local_epe=None, slot=None):
+        """local_epe: the step's vector (copied into the next payload slot).  slot: the vector is
+        already in ``payload_view(slot)`` (must be ``next_slot()``)."""
         if len(self.pending) >= 2:
             raise RuntimeError("EpeGather: collect() the oldest result before submitting a third")
         k = self.slot
+        if slot is not None:
+            if local_epe is not None:
+                raise ValueError("EpeGather.submit: pass a vector or a slot, not both")
+            if slot != k:
+                raise RuntimeError("EpeGather: slot {} submitted, slot {} is next".format(slot, k))
+        else:
+            self.payload[k][:self.L].copy_(local_epe)
         self.slot ^= 1
-        self.payload[k][:self.L].copy_(local_epe)
+        if not self.collective:
+            self.pending.append((None, self.payload[k][:self.L].clone()))
+            return
         work = dist.all_gather_into_tensor(self.flat[k], self.payload[k], async_op=True)
         self.pending.append((work, self.flat[k]))
 
@@ -113,6 +134,52 @@ class EpeGather:
 
     def outstanding(self):
         return len(self.pending)
+
+
+def timed_steps(run_step, gather, steps, warmup, device, sync=None):
+    """THE step loop of bench.py (kept here so that the CPU suite can run it under gloo with a stub
+    forward): `warmup` untimed steps, a drain, then exactly `steps` steps bracketed by a barrier and a
+    device synchronisation on both sides; the last collective is drained INSIDE the timed region.
+
+    run_step(k) runs step k's forward and returns either the step's EPE vector (a tensor, copied into the
+    payload) or the payload slot (int) it has already written in stream order.  Every step submits its
+    all-gather and, once two are outstanding, collects the older one -- the exchange of step k travels
+    while step k+1 computes.  -> (elapsed seconds, MAX over ranks; list of collected (per_rank, mean) in
+    step order for the timed steps)."""
+    if sync is None:
+        sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+
+    def step(k):
+        r = run_step(k)
+        if isinstance(r, int):
+            gather.submit(slot=r)
+        else:
+            gather.submit(r)
+        return gather.collect() if gather.outstanding() > 1 else None
+
+    def drain():
+        out = []
+        while gather.outstanding():
+            out.append(gather.collect())
+        return out
+
+    import time
+    for k in range(warmup):
+        step(k)
+    drain()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    results = []
+    for k in range(warmup, warmup + steps):
+        r = step(k)
+        if r is not None:
+            results.append(r)
+    results += drain()
+    barrier()
+    sync()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    return elapsed, results
 
 
 def barrier():

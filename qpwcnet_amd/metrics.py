@@ -23,8 +23,13 @@ def multiscale_ground_truth(flow_gt, shapes, data_format=CHANNELS_LAST):
     return out
 
 
-def per_level_epe(flows_true, flows_pred, data_format=CHANNELS_LAST):
-    """-> float32 tensor [n_levels] on the flows' device (HIP reduction kernel)."""
+def per_level_epe(flows_true, flows_pred, data_format=CHANNELS_LAST, out=None):
+    """-> float32 tensor [n_levels] on the flows' device (HIP reduction kernel); written into ``out``
+    when given (the all-gather payload, see qpwcnet_amd.dist.EpeGather.payload_view)."""
     if data_format == CHANNELS_LAST and len(flows_true) <= 8:
-        return ops.epe_multi(flows_true, flows_pred)  # all levels in two launches
-    return torch.stack([ops.epe(t, p.float(), data_format) for t, p in zip(flows_true, flows_pred)])
+        return ops.epe_multi(flows_true, flows_pred, out=out)  # all levels in two launches
+    res = torch.stack([ops.epe(t, p.float(), data_format) for t, p in zip(flows_true, flows_pred)])
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res

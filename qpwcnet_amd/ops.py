@@ -408,9 +408,11 @@ def occlusion_map(flow, data_format=CHANNELS_LAST):
     return out
 
 
-def epe_multi(flows_true, flows_pred):
+def epe_multi(flows_true, flows_pred, out=None):
     """Per-level EPE of up to 8 channels-last fp32 flow pairs in two launches
-    (FlowMseLoss, qpwcnet/train/loss.py:56-67) -> float32 tensor [n_levels]."""
+    (FlowMseLoss, qpwcnet/train/loss.py:56-67) -> float32 tensor [n_levels].
+    ``out``: dense fp32 device vector [n_levels] to write into (e.g. the all-gather payload of
+    qpwcnet_amd.dist.EpeGather, so that no copy stands between the reduction and the collective)."""
     import ctypes
     n = len(flows_true)
     if n != len(flows_pred) or not 1 <= n <= 8:
@@ -429,7 +431,10 @@ def epe_multi(flows_true, flows_pred):
     dev = keep[0].device
     L = _hip.lib()
     ws = torch.empty(L.qpwc_epe_multi_workspace_floats(), dtype=torch.float32, device=dev)
-    out = torch.empty(n, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+    elif out.dtype != torch.float32 or out.numel() != n or not out.is_contiguous() or out.device != dev:
+        raise ValueError("out must be a dense fp32 vector of {} elements on {}".format(n, dev))
     with torch.cuda.device(dev):
         rc = L.qpwc_epe_multi_fwd((ctypes.c_void_p * n)(*pa), (ctypes.c_void_p * n)(*pb),
                                   (ctypes.c_int64 * n)(*npix), n, out.data_ptr(), ws.data_ptr(),

@@ -195,6 +195,10 @@ class QpwcNet:
                 hip_chunks = (2 if li == 0 else 4) if small else 1
                 f = l.cat_skip(f, encs[i], batch_chunks=chunks, hip_chunks=hip_chunks)
                 i -= 1
+                # allocated on `side`, read by UpFlow on `main`: tell the caching allocator, so that the block
+                # is not handed to a later side-stream allocation while main may still be reading it (the
+                # join at the end orders main after side, not side's NEXT use after main's reads)
+                f.record_stream(main)
                 decs.append(f)
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -222,9 +226,13 @@ class GraphedForward:
     input shape: `replay(new_inputs)` copies into the static input and relaunches the captured
     kernels -- the launch-bound inner loop of inference (160 -> 1 host launches per batch)."""
 
-    def __init__(self, model, example_inputs, epilogue=None, warmup=3):
+    def __init__(self, model, example_inputs, epilogue=None, warmup=3, share_with=None):
+        """share_with: another GraphedForward whose static input and memory pool this one reuses (same
+        model, same shapes, another epilogue) -- the two must then be replayed alternately in capture
+        order, never concurrently (bench.py, N > 1: the two graphs differ only in the all-gather payload
+        slot their EPE reduction writes)."""
         self.model = model
-        self.static_in = example_inputs.clone()
+        self.static_in = example_inputs.clone() if share_with is None else share_with.static_in
 
         def run():
             with torch.no_grad():
@@ -240,7 +248,8 @@ class GraphedForward:
             run()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        pool = None if share_with is None else share_with.graph.pool()
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
             self.outputs, self.extra = run()
 
     def replay(self, inputs=None):

@@ -26,7 +26,8 @@ def test_header_symbols_all_exported(hip_lib):
 
 
 def test_version_and_strerror(hip_lib):
-    assert hip_lib.qpwc_version() == 100
+    assert hip_lib.qpwc_version() == 200
+    assert b"product" in hip_lib.qpwc_build_info() and b"EXPERIMENTAL" not in hip_lib.qpwc_build_info()
     assert hip_lib.qpwc_strerror(0) == b"ok"
     assert b"data format" in hip_lib.qpwc_strerror(-2)
 
@@ -54,6 +55,9 @@ def test_argument_validation_needs_no_gpu(hip_lib):
     assert L.qpwc_warp_cost_volume_fwd(p, p, None, q, 1, 2, 2, 4, 4, 0, 0.1, 81, 0, None) == _hip.E_NULL
     assert L.qpwc_epe_fwd(p, p, None, q, 1, 2, 2, 0, None) == _hip.E_NULL
     assert L.qpwc_epe_workspace_floats() > 0
+    assert L.qpwc_device_copy(p, q, 24, None) == _hip.E_SHAPE
+    assert L.qpwc_device_copy(p, p, 64, None) == _hip.E_ALIAS
+    assert L.qpwc_device_copy(None, q, 64, None) == _hip.E_NULL
 
 
 def test_check_maps_codes_to_reference_exceptions(hip_lib):

@@ -103,3 +103,78 @@ def test_world_size_2_gloo_allgather():
     np.testing.assert_allclose(m0, full0, rtol=1e-5)    # weighted mean == EPE of the whole batch
     np.testing.assert_allclose(m1, full1, rtol=1e-5)
     assert t0 == t1 == 2.0                              # max over ranks
+
+
+# ---- bench.py's real step / drain loop (qpwcnet_amd.dist.timed_steps) under world_size-2 gloo ----------
+def _loop_worker(rank, world, port, q, in_place):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+                      RANK=str(rank), LOCAL_RANK=str(rank))
+    from qpwcnet_amd import dist as qd
+    qd.init("gloo")
+    n_local = 3 if rank == 0 else 5                      # uneven shards: the mean must be weighted
+    gather = qd.EpeGather(6, "cpu", n_local=n_local)
+    calls = []
+
+    def stub_forward(k):
+        """Stand-in for one forward of step k: a vector that names its step, rank and level."""
+        return torch.arange(6, dtype=torch.float32) + 10.0 * k + 1000.0 * rank
+
+    def run_step(k):
+        calls.append(k)
+        if in_place:    # what the captured EPE reduction does on the GPU: write the payload slot itself
+            s = gather.next_slot()
+            gather.payload_view(s).copy_(stub_forward(k))
+            return s
+        return stub_forward(k)
+
+    steps, warmup = 7, 3
+    elapsed, results = qd.timed_steps(run_step, gather, steps, warmup, "cpu")
+    assert calls == list(range(warmup + steps)) and gather.outstanding() == 0
+    q.put((rank, elapsed, [(pr.numpy(), m.numpy()) for pr, m in results]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("in_place", [False, True], ids=["copied-payload", "payload-written-in-place"])
+def test_bench_step_loop_world_size_2_gloo(in_place):
+    """The loop bench.py times (warm-up, drain, barrier, K steps with the all-gather of step k collected
+    during step k+1, final drain inside the timed region, max over ranks), with a stub forward: every
+    timed step's result comes back once, in step order, holding BOTH ranks' vectors of THAT step, and the
+    drained last result is the last step's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q, in_place)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, t0, r0), (_, t1, r1) = res
+    assert t0 == t1 and t0 > 0                            # MAX over ranks, same on every rank
+    steps, warmup = 7, 3
+    assert len(r0) == len(r1) == steps
+    base = np.arange(6, dtype=np.float32)
+    for i in range(steps):
+        k = warmup + i
+        expect = np.stack([base + 10.0 * k, base + 10.0 * k + 1000.0])
+        for pr, mean in (r0[i], r1[i]):
+            np.testing.assert_array_equal(pr, expect)     # ordering: result i belongs to step warmup + i
+            np.testing.assert_allclose(mean, (3 * expect[0] + 5 * expect[1]) / 8, rtol=1e-6)
+
+
+def test_epe_gather_slot_protocol():
+    eg = qdist.EpeGather(3, "cpu")
+    assert eg.next_slot() == 0
+    eg.payload_view(0).copy_(torch.tensor([1.0, 2.0, 3.0]))
+    eg.submit(slot=0)
+    with pytest.raises(RuntimeError):
+        eg.submit(slot=0)                                 # slot 1 is next
+    eg.payload_view(1).copy_(torch.tensor([4.0, 5.0, 6.0]))
+    eg.submit(slot=1)
+    with pytest.raises(RuntimeError):
+        eg.submit(torch.zeros(3))                         # at most two outstanding
+    assert torch.equal(eg.collect()[1], torch.tensor([1.0, 2.0, 3.0]))
+    assert torch.equal(eg.collect()[1], torch.tensor([4.0, 5.0, 6.0]))
+    with pytest.raises(ValueError):
+        eg.submit(torch.zeros(3), slot=0)

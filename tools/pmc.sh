@@ -2,12 +2,21 @@
 # PMC counter passes with rocprofv3 (counters in their own runs, no trace domains
 # besides --kernel-trace).  Usage: tools/pmc.sh <tag> -- <program> [args...]
 # Results: gpurun_out/pmc_<tag>/<pass>/.../*_counter_collection.csv
+# The program's arguments are resolved against the repo root BEFORE the cd to /tmp (rocprofv3 wants a
+# writable cwd): a relative script path such as tools/sepbench.py keeps working.  Exit status: non-zero
+# if any pass failed.
 set -u
 tag=$1; shift; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/pmc_$tag
 mkdir -p "$out"
+args=()
+for a in "$@"; do
+  if [[ "$a" != /* && "$a" != -* && -e "$root/$a" ]]; then args+=("$root/$a"); else args+=("$a"); fi
+done
+set -- "${args[@]}"
 cd /tmp && export TMPDIR=/tmp
+failed=0
 passes=(
  "A:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES"
  "B:SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
@@ -19,6 +28,7 @@ passes=(
 )
 for p in "${passes[@]}"; do
   name=${p%%:*}; ctrs=${p#*:}
-  timeout -k 10 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out/$name" -- "$@" > "$out/$name.log" 2>&1 || echo "pass $name failed (see $out/$name.log)"
+  timeout -k 10 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out/$name" -- "$@" > "$out/$name.log" 2>&1 || { echo "pass $name failed (see $out/$name.log)"; failed=1; }
 done
-echo "pmc passes done -> $out"
+echo "pmc passes done -> $out (failed=$failed)"
+exit $failed
