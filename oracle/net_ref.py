@@ -42,21 +42,38 @@ def mish(x):
 
 
 class RefNet:
-    def __init__(self, weights, dtype=torch.float32):
+    """storage="fp16": the same graph with the ROUNDING POINTS of an fp16-storage deployment restated
+    on it (BASELINE configs[4]; the reference itself has no fp16 path): weights and inputs rounded to
+    fp16, every tensor a layer hands to the next one rounded to fp16 (conv + bias + Mish outputs, the
+    depthwise and the pointwise halves of a SeparableConv2D, cost volume, warp, flow, upsampled flow),
+    all arithmetic in between in fp32.  It is what an fp16 implementation must agree with up to
+    accumulation order and the placement of a rounding before or after an activation -- the derived
+    bound of tests/test_gpu_configs.py -- whereas its distance from the fp32 graph is fp16's own noise."""
+
+    def __init__(self, weights, dtype=torch.float32, storage="fp32"):
         self.dtype = dtype
+        if storage not in ("fp32", "fp16"):
+            raise ValueError("storage must be 'fp32' or 'fp16'")
+        self.fp16 = storage == "fp16"
         self.w = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in weights.items()}
+        if self.fp16:
+            self.w = {k: v.half().to(dtype) for k, v in self.w.items()}
+
+    def q(self, x):
+        """A storage point: identity in fp32, round-to-nearest fp16 otherwise."""
+        return x.half().to(x.dtype) if self.fp16 else x
 
     def down_conv(self, i, x):                      # non_layers.py:390-449, no normalizer
         y = _c(x)
         for name, s in (("conv_a", 2), ("conv_aa", 1), ("conv_b", 1)):
             p = "enc.{}.{}".format(i, name)
-            y = mish(_tf_same_conv(y, self.w[p + ".weight"], self.w[p + ".bias"], s))
+            y = self.q(mish(_tf_same_conv(y, self.w[p + ".weight"], self.w[p + ".bias"], s)))
         return _l(y)
 
     def up_conv(self, i, x):                        # non_layers.py:196-210
         p = "dec.{}.conv_up".format(i)
         y = F.conv_transpose2d(_c(x), self.w[p + ".weight"], self.w[p + ".bias"], stride=2, padding=1)
-        return _l(mish(y))
+        return _l(self.q(mish(y)))
 
     def opt_flow(self, prefix, feat):               # non_layers.py:213-273
         h, w = feat.shape[1], feat.shape[2]
@@ -64,27 +81,26 @@ class RefNet:
         x = _c(feat)
         for i in range(4):
             dw = self.w["{}feat.{}.depthwise.weight".format(prefix, i)]
-            x = F.conv2d(x, dw, None, padding=1, groups=dw.shape[0])
+            x = self.q(F.conv2d(x, dw, None, padding=1, groups=dw.shape[0]))
             x = F.conv2d(x, self.w["{}feat.{}.pointwise.weight".format(prefix, i)],
                          self.w["{}feat.{}.bias".format(prefix, i)])
-            x = mish(x)
+            x = self.q(mish(x))
         x = mish(F.conv2d(x, self.w[prefix + "conv.weight"], self.w[prefix + "conv.bias"]))
         g, b = self.w[prefix + "norm.gamma"], self.w[prefix + "norm.beta"]
         m, v = self.w[prefix + "norm.mean"], self.w[prefix + "norm.var"]
         x = (x - m.view(1, -1, 1, 1)) / torch.sqrt(v.view(1, -1, 1, 1) + BN_EPS) \
             * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
         f = F.conv2d(x, self.w[prefix + "flow.weight"], None, padding=1)
-        return _l(scale * f)
+        return _l(self.q(scale * f))
 
-    @staticmethod
-    def upsample(x, scale):                         # non_layers.py:183-193
+    def upsample(self, x, scale):                   # non_layers.py:183-193
         y = F.interpolate(_c(x), scale_factor=2, mode="bilinear", align_corners=False)
-        return _l(scale * y)
+        return _l(self.q(scale * y))
 
     @torch.no_grad()
     def __call__(self, inputs):
         """inputs (B,H,W,6) -> list of the 6 multi-scale flows (pwcnet.py:28-67)."""
-        x = torch.as_tensor(inputs).to(self.dtype)
+        x = self.q(torch.as_tensor(inputs).to(self.dtype))
         img_prv, img_nxt = x[..., :3], x[..., 3:]   # Split(2), pwcnet.py:229
         encs = []
         for img in (img_prv, img_nxt):              # pwcnet.py:134-168 (shared weights)
@@ -102,14 +118,14 @@ class RefNet:
                 out.append(f)
             decs.append(out)
         prv, nxt = encs[0][-1], encs[1][-1]
-        cost = torch_ref.cost_volume(prv, nxt)      # Flow, non_layers.py:332-338
+        cost = self.q(torch_ref.cost_volume(prv, nxt))      # Flow, non_layers.py:332-338
         flo = self.opt_flow("flow.flow.", torch.cat([cost, prv, nxt], dim=3))
         flos = [flo]
         for i in range(DEC):                        # pwcnet.py:43-57
             flo_u = self.upsample(flo, 2.0)
             prv, nxt = decs[0][i], decs[1][i]
-            nxt_w = torch_ref.warp_v2(nxt, flo_u)   # UpFlow, non_layers.py:377-385
-            cost = torch_ref.cost_volume(prv, nxt_w)
+            nxt_w = self.q(torch_ref.warp_v2(nxt, flo_u))   # UpFlow, non_layers.py:377-385
+            cost = self.q(torch_ref.cost_volume(prv, nxt_w))
             flo = self.opt_flow("upflow.{}.flow.".format(i), torch.cat([cost, prv, flo_u], dim=3))
             flos.append(flo)
         flos.append(self.upsample(flo, 2.0))        # pwcnet.py:60

@@ -1,0 +1,214 @@
+"""GPU suite (-m gpu): BASELINE.json configs[3] (batch 16, 1024x2048 fp32) and configs[4] (batch 32,
+256x512, fp16 storage) on THEIR OWN workload sizes -- the hot-path kernels at the configs' level shapes
+and batch sizes against the C oracle, and the full network through hipGraph replay against the CPU
+restatement on a subset of the batch (the oracle finishes in seconds on 2-4 pairs, not on 32).
+
+fp16 bounds are derived, not chosen: the oracle is run with the same ROUNDING POINTS as the fp16-storage
+deployment (oracle/net_ref.py: RefNet(storage="fp16") -- fp16 inputs / weights / activations, fp32
+arithmetic), so what is left between the GPU and that oracle is accumulation order and the placement of
+a rounding before or after an activation, i.e. the same size as fp16's own noise, which the test
+measures as the distance between the fp16-point oracle and the fp32 oracle.  A negative control (one
+layer's weights off by 10 %) must violate the bound at that layer's level, so a wrong layer cannot pass
+(later levels re-estimate the residual flow and largely repair an upstream error: the check is per level).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_ref, net_ref, torch_ref
+from qpwcnet_amd import metrics, non_layers, ops, synth
+from qpwcnet_amd.pwcnet import GraphedForward, build_flower
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4      # north_star: fp32 outputs within 1e-4 of the reference algorithm
+LEVELS_256 = [(8, 16, 256), (16, 32, 256), (32, 64, 128), (64, 128, 64), (128, 256, 32)]
+F16_EPS = 2.0 ** -11    # half an fp16 ulp, relative
+
+
+def gpu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _loaded():
+    from qpwcnet_amd import _hip
+    _hip.lib()
+    c_ref.build()
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[4]: fp16 storage, batch 32, the five 256x512 level shapes
+@pytest.mark.parametrize("hwc", LEVELS_256, ids=["L0", "L1", "L2", "L3", "L4"])
+def test_config5_level_shapes_batch32_fp16(hwc):
+    """Cost volume and WarpV2 at (32, H, W, C) fp16 -- the launches the config's step makes.  Oracle: the
+    C restatement on the fp16-rounded inputs (exactly representable in fp32) for the first and the last
+    pair of the batch; every other pair through batch independence (launch of 32 == launch of 1, bit for
+    bit).  Bound: the output's own fp16 rounding (|x| * 2^-11) + the fp32 tolerance of north_star."""
+    H, W, C = hwc
+    B = 32
+    g = torch.Generator(device=DEV).manual_seed(500 + H)
+    prv = torch.randn(B, H, W, C, device=DEV, generator=g).half()
+    nxt = torch.randn(B, H, W, C, device=DEV, generator=g).half()
+    flo = torch.randn(B, H, W, 2, device=DEV, generator=g) * 4
+    cv = ops.cost_volume(prv, nxt)
+    wv = ops.warp(nxt, flo, "clamp")
+    assert cv.dtype == torch.float16 and wv.dtype == torch.float16
+    for b in (0, B - 1):
+        p32, n32 = prv[b:b + 1].float().cpu().numpy(), nxt[b:b + 1].float().cpu().numpy()
+        f32 = flo[b:b + 1].cpu().numpy()
+        ref = c_ref.cost_volume(p32, n32)
+        got = cv[b:b + 1].float().cpu().numpy()
+        assert np.all(np.abs(got - ref) <= F16_EPS * np.abs(ref) + TOL), "pair {} cost volume".format(b)
+        # warp: same fp32 op sequence on both sides, then ONE rounding to fp16 -> bit-exact
+        wref = c_ref.warp(n32, f32).astype(np.float16)
+        np.testing.assert_array_equal(wv[b:b + 1].cpu().numpy(), wref, err_msg="pair {} warp".format(b))
+    for b in (1, 13, 30):
+        assert torch.equal(cv[b:b + 1], ops.cost_volume(prv[b:b + 1].contiguous(), nxt[b:b + 1].contiguous()))
+        assert torch.equal(wv[b:b + 1], ops.warp(nxt[b:b + 1].contiguous(), flo[b:b + 1].contiguous(), "clamp"))
+    # the 84-half padded volume the fused first OptFlow layer reads (the step's own launch form)
+    buf = torch.full((B, H, W, 84), float("nan"), device=DEV, dtype=torch.float16)
+    ops.cost_volume_into(prv, nxt, buf, 0)
+    assert torch.equal(buf[..., :81], cv) and float(buf[..., 81:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("level", [4, 3], ids=["L4", "L3"])
+def test_config5_fused_sepconv_batch32_fp16(level):
+    """First SeparableConv2D of the level's OptFlow at batch 32, fp16: [cost84 | prv | flo] -> 128 through
+    qpwc_sepconv3x3_f16_fwd, against the oracle's ops with the kernel's rounding points (fp16 inputs and
+    pointwise weights, depthwise result rounded to fp16 once, fp32 accumulation), on pairs 0 and 31."""
+    H, W, C = LEVELS_256[level]
+    B, F_ = 32, 128
+    rng = np.random.default_rng(70 + level)
+    g = torch.Generator(device=DEV).manual_seed(70 + level)
+    cost = torch.randn(B, H, W, 84, device=DEV, generator=g).half()
+    cost[..., 81:] = 0
+    prv = torch.randn(B, H, W, C, device=DEV, generator=g).half()
+    flo = (torch.randn(B, H, W, 2, device=DEV, generator=g) * 4).half()
+    Ct = 84 + C + 2
+    dw = torch.from_numpy(rng.standard_normal((Ct, 1, 3, 3)).astype(np.float32))
+    pw = torch.from_numpy((rng.standard_normal((F_, Ct, 1, 1)) / np.sqrt(Ct)).astype(np.float32)).half()
+    bias = torch.from_numpy(rng.standard_normal(F_).astype(np.float32))
+    out = ops.sepconv3x3([cost, prv, flo], dw.to(DEV), ops.pad_pointwise(pw.to(DEV), torch.float16), bias.to(DEV),
+                         mish_on_store=True)
+    assert out.dtype == torch.float16 and tuple(out.shape) == (B, H, W, F_)
+    for b in (0, B - 1):
+        srcs = [t[b:b + 1].float().cpu() for t in (cost, prv, flo)]
+        y = torch_ref.depthwise3x3(srcs, dw).half().float()
+        ref = torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw.float(), bias).permute(0, 2, 3, 1)
+        # depthwise sums on an fp16 rounding boundary may round the other way (fma order): 2 ulp + abs floor
+        torch.testing.assert_close(out[b:b + 1].float().cpu(), torch_ref.mish(ref), rtol=2e-3, atol=4e-3)
+    one = ops.sepconv3x3([cost[7:8].contiguous(), prv[7:8].contiguous(), flo[7:8].contiguous()], dw.to(DEV),
+                         ops.pad_pointwise(pw.to(DEV), torch.float16), bias.to(DEV), mish_on_store=True)
+    assert torch.equal(out[7:8], one)
+
+
+def _epes(flows_a, flows_b):
+    return [float(torch_ref.epe_error(a.float().cpu(), b.float().cpu())) for a, b in zip(flows_a, flows_b)]
+
+
+def test_config5_full_network_batch32_fp16_graph_vs_fp16_point_oracle():
+    """BASELINE configs[4] as bench.py runs it: batch 32, 256x512, fp16 storage, one hipGraph replay.
+    Per-level EPE of pairs {0, 13, 31} against the oracle with fp16 rounding points; the bound is the
+    oracle's own fp16 noise (distance fp16-point oracle <-> fp32 oracle) plus half an fp16 ulp of the flow
+    itself, and a 10 % error in ONE layer of the oracle must break it at that layer's level."""
+    hw, B = (256, 512), 32
+    weights = synth.make_weights(42, hw)
+    pairs, gt = synth.make_frames(B, hw[0], hw[1], seed=1234)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV, dtype=torch.float16)
+    x = torch.from_numpy(pairs).to(DEV, torch.float16)
+    graph = GraphedForward(model, x)
+    flows, _ = graph.replay(x)
+    assert all(f.dtype == torch.float16 and f.shape[0] == B for f in flows)
+    assert all(bool(torch.isfinite(f).all()) for f in flows)
+    sub = [0, 13, 31]
+    sel = pairs[sub]
+    ref16 = net_ref.RefNet(weights, storage="fp16")(sel)
+    ref32 = net_ref.RefNet(weights)(sel)
+    got = [f[sub] for f in flows]
+    e_gpu = _epes(got, ref16)          # GPU vs the oracle with the same rounding points
+    noise = _epes(ref16, ref32)        # what fp16 storage itself costs
+    mags = [float(torch.linalg.vector_norm(r, dim=-1).mean()) for r in ref32]
+    # negative control: the same oracle with ONE pointwise layer 10 % off
+    bad_w = dict(weights)
+    k = "upflow.1.flow.feat.1.pointwise.weight"
+    bad_w[k] = np.asarray(weights[k]) * 1.10
+    e_bad = _epes(got, net_ref.RefNet(bad_w, storage="fp16")(sel))
+    report = "per level: GPU-vs-fp16-oracle {} | fp16 noise {} | 10%-wrong-layer {} | |flow| {}".format(
+        ["%.2e" % v for v in e_gpu], ["%.2e" % v for v in noise], ["%.2e" % v for v in e_bad],
+        ["%.2e" % v for v in mags])
+    print(report)
+    for lvl in range(6):
+        bound = 1.5 * noise[lvl] + F16_EPS * mags[lvl]
+        assert e_gpu[lvl] <= bound, "level {}: {} > {} ({})".format(lvl, e_gpu[lvl], bound, report)
+    # the wrong layer sits at level 2 (upflow.1): there the bound must fail
+    bound = 1.5 * noise[2] + F16_EPS * mags[2]
+    assert e_bad[2] > 2 * bound, "negative control passes at level 2 ({})".format(report)
+    # and the flows are sane against the synthetic ground truth the frames were made from
+    gt_pyr = metrics.multiscale_ground_truth(torch.from_numpy(gt).to(DEV),
+                                             [(hw[0] >> s, hw[1] >> s) for s in (5, 4, 3, 2, 1, 0)])
+    assert bool(torch.isfinite(metrics.per_level_epe(gt_pyr, flows)).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[3]: batch 16, 1024x2048 fp32 -- finest level (16, 512, 1024, 32): 1.07 GB per operand,
+# 2.72 GB of cost volume, output byte offsets beyond 2^31
+def test_config4_finest_level_batch16_crops_and_properties():
+    B, H, W, C = 16, 512, 1024, 32
+    g = torch.Generator(device=DEV).manual_seed(4)
+    prv = torch.randn(B, H, W, C, device=DEV, generator=g)
+    nxt = torch.randn(B, H, W, C, device=DEV, generator=g)
+    flo = torch.randn(B, H, W, 2, device=DEV, generator=g) * 4
+    cv = ops.cost_volume(prv, nxt)
+    assert cv.numel() * 4 > 2 ** 31
+    # oracle crops at both ends of the batch: top-left corner of pair 0 and bottom-right corner of pair 15
+    # (the element with the largest offset of the launch), each including the image border it touches
+    S = 48
+
+    def crop_check(b, ys, xs, valid):
+        ref = c_ref.cost_volume(prv[b:b + 1, ys, xs].cpu().numpy(), nxt[b:b + 1, ys, xs].cpu().numpy())
+        got = cv[b:b + 1, ys, xs].cpu().numpy()
+        np.testing.assert_allclose(got[:, valid[0], valid[1]], ref[:, valid[0], valid[1]], rtol=0, atol=TOL,
+                                   err_msg="pair {}".format(b))
+    crop_check(0, slice(0, S), slice(0, S), (slice(0, S - 8), slice(0, S - 8)))
+    crop_check(B - 1, slice(H - S, H), slice(W - S, W), (slice(8, S), slice(8, S)))
+    crop_check(7, slice(200, 200 + S), slice(500, 500 + S), (slice(8, S - 8), slice(8, S - 8)))
+    # batch independence across the whole batch (one launch of 16 == 16 launches of 1, bit for bit)
+    for b in (0, 5, B - 1):
+        assert torch.equal(cv[b:b + 1], ops.cost_volume(prv[b:b + 1].contiguous(), nxt[b:b + 1].contiguous()))
+    # zero padding at the far corner: displacement (+4,+4) = channel 80 of the last pixel of pair 15
+    assert float(cv[B - 1, H - 1, W - 1, 80].abs()) == 0.0 and float(cv[0, 0, 0, 0].abs()) == 0.0
+    del cv
+    # the step's own launch form: 84-float pixels, pads zero, same values
+    buf = torch.empty(B, H, W, 84, device=DEV)
+    ops.cost_volume_into(prv, nxt, buf, 0)
+    assert float(buf[..., 81:].abs().max()) == 0.0
+    assert torch.equal(buf[B - 1:, :, :, :81], ops.cost_volume(prv[B - 1:].contiguous(), nxt[B - 1:].contiguous()))
+    del buf
+    # WarpV2: bit-exact against the C oracle for whole pairs at both ends of the batch
+    wv = ops.warp(nxt, flo, "clamp")
+    for b in (0, B - 1):
+        np.testing.assert_array_equal(wv[b:b + 1].cpu().numpy(),
+                                      c_ref.warp(nxt[b:b + 1].cpu().numpy(), flo[b:b + 1].cpu().numpy()))
+    # fused front end == warp then cost volume, far end of the batch
+    fused = ops.warp_cost_volume(prv, nxt, flo)
+    unf = ops.cost_volume(prv[B - 1:].contiguous(), wv[B - 1:].contiguous())
+    assert float((fused[B - 1:] - unf).abs().max()) <= 1e-5
+
+
+def test_config4_full_network_batch16_graph_first_and_last_pair():
+    """BASELINE configs[3] as bench.py runs it (batch 16, 1024x2048 fp32, hipGraph replay): per-level EPE
+    of the first and the last pair of the batch against the CPU restatement, 1e-4."""
+    hw, B = (1024, 2048), 16
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(B, hw[0], hw[1], seed=3)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV)
+    x = torch.from_numpy(pairs).to(DEV)
+    graph = GraphedForward(model, x)
+    flows, _ = graph.replay(x)
+    sub = [0, B - 1]
+    ref = net_ref.RefNet(weights)(pairs[sub])
+    for lvl, (a, b) in enumerate(zip(flows, ref)):
+        assert a.shape[0] == B
+        e = float(torch_ref.epe_error(a[sub].cpu(), b))
+        assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
