@@ -43,8 +43,7 @@ def _loaded():
 def test_config5_level_shapes_batch32_fp16(hwc):
     """Cost volume and WarpV2 at (32, H, W, C) fp16 -- the launches the config's step makes.  Oracle: the
     C restatement on the fp16-rounded inputs (exactly representable in fp32) for the first and the last
-    pair of the batch; every other pair through batch independence (launch of 32 == launch of 1, bit for
-    bit).  Bound: the output's own fp16 rounding (|x| * 2^-11) + the fp32 tolerance of north_star."""
+    pair of the batch; other pairs through batch independence (launch of 32 vs launch of 1).  Bound: the output's own fp16 rounding (|x| * 2^-11) + the fp32 tolerance of north_star."""
     H, W, C = hwc
     B = 32
     g = torch.Generator(device=DEV).manual_seed(500 + H)
@@ -64,7 +63,10 @@ def test_config5_level_shapes_batch32_fp16(hwc):
         wref = c_ref.warp(n32, f32).astype(np.float16)
         np.testing.assert_array_equal(wv[b:b + 1].cpu().numpy(), wref, err_msg="pair {} warp".format(b))
     for b in (1, 13, 30):
-        assert torch.equal(cv[b:b + 1], ops.cost_volume(prv[b:b + 1].contiguous(), nxt[b:b + 1].contiguous()))
+        # a launch of one pair may take another kernel (split-K over the channels at the coarse levels):
+        # same sums in another order, then the same fp16 rounding -> at most an ulp apart
+        one = ops.cost_volume(prv[b:b + 1].contiguous(), nxt[b:b + 1].contiguous())
+        torch.testing.assert_close(cv[b:b + 1].float(), one.float(), rtol=2 * F16_EPS, atol=1e-5)
         assert torch.equal(wv[b:b + 1], ops.warp(nxt[b:b + 1].contiguous(), flo[b:b + 1].contiguous(), "clamp"))
     # the 84-half padded volume the fused first OptFlow layer reads (the step's own launch form)
     buf = torch.full((B, H, W, 84), float("nan"), device=DEV, dtype=torch.float16)
