@@ -389,11 +389,11 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
     gt = torch.from_numpy(gt_np).to(dev)
     shapes = [(hw[0] >> s, hw[1] >> s) for s in (5, 4, 3, 2, 1, 0)]
     gt_pyr = metrics.multiscale_ground_truth(gt, shapes)
+    if not cl:   # the model's flows are (B,2,h,w): so is the ground truth, the reduction reads planes
+        gt_pyr = [g.permute(0, 3, 1, 2).contiguous() for g in gt_pyr]
 
     def epe_of(flows, out=None):
-        if not cl:   # the EPE reduction takes channels-last flows (2 channels: a cheap view-copy)
-            flows = [f.permute(0, 2, 3, 1) for f in flows]
-        return metrics.per_level_epe(gt_pyr, flows, out=out)
+        return metrics.per_level_epe(gt_pyr, flows, data_format=args.data_format, out=out)
 
     def forward():
         with torch.no_grad():

@@ -64,6 +64,13 @@ const char* qpwc_strerror(int code);
  * keeps A/B switches and reports "EXPERIMENTAL" here. */
 const char* qpwc_build_info(void);
 
+/* Layout conversion at the boundary: out = in with the same logical (B,H,W,C) content in `to_layout`
+ * (in is in the other layout).  The reference picks its layout from image_data_format()
+ * (qpwcnet/core/layers.py:41,146; NCHW handled by transposing in and out, layers.py:179-183); the hot-path
+ * kernels are channels-last, so a dense 'channels_first' tensor crosses the boundary through this kernel. */
+int qpwc_layout_transpose_fwd(const void* in, void* out, int B, int H, int W, int C, int to_layout, int dtype,
+                              void* stream);
+
 /* Measurement aid ("measure the achievable ceiling on the box with a device copy
  * kernel"): dst[0..bytes) = src[0..bytes), 16 B per lane, bytes % 16 == 0, both 16-byte aligned.
  * Not part of the reference's surface. */
@@ -129,12 +136,14 @@ int qpwc_epe_fwd(const void* y_true, const void* y_pred, void* out_mean, void* w
                  int B, int H, int W, int layout, void* stream);
 
 /* Multi-scale form (FlowMseLoss.call, qpwcnet/train/loss.py:56-67): the EPE of n_levels
- * (<= 8) channels-last fp32 flow pairs y_true[i], y_pred[i] with n_pixels[i] = B*h_i*w_i
- * each, in two launches.  out_means: n_levels floats; workspace:
- * >= qpwc_epe_multi_workspace_floats() floats. */
+ * (<= 8) fp32 flow pairs y_true[i], y_pred[i] with n_pixels[i] = B*h_i*w_i each, in two
+ * launches.  plane_pixels: NULL or all zero = channels-last (B,h,w,2) flows; plane_pixels[i] =
+ * h_i*w_i > 0 = 'channels_first' (B,2,h,w) flows at that level.  out_means: n_levels floats;
+ * workspace: >= qpwc_epe_multi_workspace_floats() floats. */
 int qpwc_epe_multi_workspace_floats(void);
 int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
-                       int n_levels, void* out_means, void* workspace, void* stream);
+                       const int64_t* plane_pixels, int n_levels, void* out_means, void* workspace,
+                       void* stream);
 
 /* cost_volume_to_flow (qpwcnet/core/vis.py:9-34): flow[b,y,x] = (di, dj), the (row, column) displacement
  * of the first maximum over the D = d*d channels of a cost volume: imax = argmax_k, q = sqrt(D),
@@ -189,10 +198,12 @@ int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels,
  *   flow = scale * conv3x3_{16->2, no bias, 'same'}( BN( Mish( W1 * Mish(z) + b1 ) ) )
  * params (device fp32, qpwc_flow_head_param_floats() = 592 floats):
  *   w1[16][16] (out,in) | b1[16] | bn_scale[16] | bn_shift[16] | wf[3][3][16][2] (ky,kx,in,out)
- * with bn_scale = gamma/sqrt(var+eps), bn_shift = beta - mean*bn_scale.  out: (B,H,W,2). */
+ * with bn_scale = gamma/sqrt(var+eps), bn_shift = beta - mean*bn_scale.
+ * out: (B,H,W,2) for out_layout QPWC_NHWC, (B,2,H,W) for QPWC_NCHW (a 'channels_first' model's flow
+ * output, written by the kernel itself instead of by a transposition launch). */
 int qpwc_flow_head_param_floats(void);
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W,
-                       float scale, int dtype, void* stream);
+                       float scale, int dtype, int out_layout, void* stream);
 
 /* x = Mish(x + bias[c]) in place, channels-last fp32 (n_pixels, C), C % 4 == 0, bias may
  * be NULL: the `activation='Mish'` epilogue of the reference's Conv2D / Conv2DTranspose /
@@ -217,9 +228,9 @@ int qpwc_split_frames_pad_fwd(const void* in, void* out, int B, int H, int W, in
 
 /* Upsample(scale) of a flow field (non_layers.py:183-193; pwcnet.py:55,60):
  * out (B,2h,2w,2) = scale * bilinear x2 upsampling (half-pixel centres, edge clamp) of
- * in (B,h,w,2), fp32 channels-last. */
+ * in (B,h,w,2); in_layout / out_layout QPWC_NCHW read (B,2,h,w) / write (B,2,2h,2w) instead. */
 int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, int dtype,
-                             void* stream);
+                             int in_layout, int out_layout, void* stream);
 
 /* inv_flow = -tf_warp(flow, flow) (occlusion.py:85; app/test/test_invert_flow.py:47): the flow
  * field sampled at its own targets with the tf_warp rules (warp.py:63-153), negated.
@@ -245,10 +256,12 @@ int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, v
 /* First encoder layer on the raw input pair: Split(2) (pwcnet.py:229) + both frames stacked on the
  * batch axis (shared encoder weights, pwcnet.py:145-162) + enc.0.conv_a = Conv2D(3 -> 16, 3x3, stride 2,
  * padding='same' [TensorFlow: 0 before, 1 after for even H, W], activation='Mish')
- * (non_layers.py:402-409):  pairs (B,H,W,6) fp32, H and W even  ->  out (2B, H/2, W/2, 16), frame f of
- * pair b at f*B + b.  weight: (9, 16, 4) fp32 = [ky*3+kx][out][in, slot 3 = 0]; bias (16). */
+ * (non_layers.py:402-409):  pairs (B,H,W,6) fp32 (layout QPWC_NHWC) or (B,6,H,W) (QPWC_NCHW, the
+ * reference's inference default, app/optical_flow/test_infer.py:52), H and W even  ->  out
+ * (2B, H/2, W/2, 16) channels-last, frame f of pair b at f*B + b.
+ * weight: (9, 16, 4) fp32 = [ky*3+kx][out][in, slot 3 = 0]; bias (16). */
 int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,
-                             int H, int W, void* stream);
+                             int H, int W, int layout, void* stream);
 
 /* conv_a of the second encoder level: Conv2D(16 -> 32, 3x3, stride 2, padding='same', activation='Mish')
  * (non_layers.py:402-409) on the zero-bordered output of qpwc_conv3x3_mish_fwd (pad 1, 1):

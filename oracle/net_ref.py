@@ -93,9 +93,10 @@ class RefNet:
         f = F.conv2d(x, self.w[prefix + "flow.weight"], None, padding=1)
         return _l(self.q(scale * f))
 
-    def upsample(self, x, scale):                   # non_layers.py:183-193
+    @staticmethod
+    def upsample(x, scale):                         # non_layers.py:183-193
         y = F.interpolate(_c(x), scale_factor=2, mode="bilinear", align_corners=False)
-        return _l(self.q(scale * y))
+        return _l(scale * y)
 
     @torch.no_grad()
     def __call__(self, inputs):
@@ -122,13 +123,13 @@ class RefNet:
         flo = self.opt_flow("flow.flow.", torch.cat([cost, prv, nxt], dim=3))
         flos = [flo]
         for i in range(DEC):                        # pwcnet.py:43-57
-            flo_u = self.upsample(flo, 2.0)
+            flo_u = self.q(self.upsample(flo, 2.0))
             prv, nxt = decs[0][i], decs[1][i]
             nxt_w = self.q(torch_ref.warp_v2(nxt, flo_u))   # UpFlow, non_layers.py:377-385
             cost = self.q(torch_ref.cost_volume(prv, nxt_w))
             flo = self.opt_flow("upflow.{}.flow.".format(i), torch.cat([cost, prv, flo_u], dim=3))
             flos.append(flo)
-        flos.append(self.upsample(flo, 2.0))        # pwcnet.py:60
+        flos.append(self.q(self.upsample(flo, 2.0)))        # pwcnet.py:60
         return flos
 
 

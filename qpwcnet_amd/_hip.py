@@ -22,7 +22,7 @@ _ARGUMENT_ERRORS = {E_NULL, E_LAYOUT, E_DTYPE, E_SHAPE, E_RANGE, E_MODE, E_ALIAS
 
 # every symbol include/qpwc.h declares
 SYMBOLS = (
-    "qpwc_version", "qpwc_last_error", "qpwc_strerror", "qpwc_build_info", "qpwc_device_copy",
+    "qpwc_version", "qpwc_last_error", "qpwc_strerror", "qpwc_build_info", "qpwc_device_copy", "qpwc_layout_transpose_fwd",
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_bias_mish_fwd",
@@ -72,6 +72,8 @@ def lib():
     L.qpwc_strerror.restype = ctypes.c_char_p
     L.qpwc_build_info.argtypes = []
     L.qpwc_build_info.restype = ctypes.c_char_p
+    L.qpwc_layout_transpose_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    L.qpwc_layout_transpose_fwd.restype = ci
     L.qpwc_device_copy.argtypes = [vp, vp, i64, vp]
     L.qpwc_device_copy.restype = ci
     L.qpwc_cost_volume_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp]
@@ -91,15 +93,16 @@ def lib():
     L.qpwc_dwconv3x3_fwd.restype = ci
     L.qpwc_flow_head_param_floats.argtypes = []
     L.qpwc_flow_head_param_floats.restype = ci
-    L.qpwc_flow_head_fwd.argtypes = [vp, vp, vp, ci, ci, ci, cf, ci, vp]
+    L.qpwc_flow_head_fwd.argtypes = [vp, vp, vp, ci, ci, ci, cf, ci, ci, vp]
     L.qpwc_flow_head_fwd.restype = ci
     L.qpwc_bias_mish_fwd.argtypes = [vp, vp, i64, ci, ci, vp]
     L.qpwc_bias_mish_fwd.restype = ci
-    L.qpwc_upsample2x_flow_fwd.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp]
+    L.qpwc_upsample2x_flow_fwd.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, ci, vp]
     L.qpwc_upsample2x_flow_fwd.restype = ci
     L.qpwc_epe_multi_workspace_floats.argtypes = []
     L.qpwc_epe_multi_workspace_floats.restype = ci
-    L.qpwc_epe_multi_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64), ci, vp, vp, vp]
+    L.qpwc_epe_multi_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64),
+                                     ctypes.POINTER(i64), ci, vp, vp, vp]
     L.qpwc_epe_multi_fwd.restype = ci
     L.qpwc_sepconv3x3_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(i64),
                                       ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -118,7 +121,7 @@ def lib():
     L.qpwc_occlusion_fwd.restype = ci
     L.qpwc_conv3x3_mish_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.qpwc_conv3x3_mish_fwd.restype = ci
-    L.qpwc_first_conv_mish_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp]
+    L.qpwc_first_conv_mish_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.qpwc_first_conv_mish_fwd.restype = ci
     L.qpwc_conv3x3s2_mish_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp]
     L.qpwc_conv3x3s2_mish_fwd.restype = ci

@@ -36,8 +36,10 @@ int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int
                int layout, hipStream_t s);
 
 int epe_multi_workspace_floats();
-int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, int n_levels,
-                     float* out, float* ws, hipStream_t s);
+int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, const int64_t* plane,
+                     int n_levels, float* out, float* ws, hipStream_t s);
+int layout_transpose_launch(const void* in, void* out, int B, int H, int W, int C, int to_layout, int dtype,
+                            hipStream_t s);
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
                      int act, const void* weight, void* out, int B, int H, int W, int dtype,
                      hipStream_t s);
@@ -50,10 +52,10 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
                       int act, const void* dw, const void* pw, const void* bias, void* out, int B, int H,
                       int W, int F, hipStream_t s);
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
-                     int dtype, hipStream_t s);
+                     int dtype, int out_layout, hipStream_t s);
 int flow_head_param_floats();
 int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, int dtype,
-                           hipStream_t s);
+                           int in_layout, int out_layout, hipStream_t s);
 int bias_mish_pad_launch(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
                          int pad_h, int pad_w, int64_t dst_pixel_stride, int dtype, hipStream_t s);
 int split_frames_pad_launch(const void* in, void* out, int B, int H, int W, int pad_h, int pad_w, int dtype,
@@ -69,7 +71,7 @@ int conv3x3s2_mish_any_launch(const void* x, const void* weight, const void* bia
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s);
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
-                           hipStream_t s);
+                           int layout, hipStream_t s);
 int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                           hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
@@ -155,6 +157,17 @@ using namespace qpwc;
 extern "C" {
 
 int qpwc_version(void) { return QPWC_VERSION; }
+
+int qpwc_layout_transpose_fwd(const void* in, void* out, int B, int H, int W, int C, int to_layout, int dtype,
+                              void* stream) {
+    if (!in || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    const int rc = check_common(B, H, W, C, to_layout, dtype);
+    if (rc) return rc;
+    const size_t es = esize(dtype), n = (size_t)B * H * W * C * es;
+    if ((uintptr_t)in % es || (uintptr_t)out % es) return fail(QPWC_E_ALIGN, "pointer not aligned to its element size");
+    if (overlaps(out, n, in, n)) return fail(QPWC_E_ALIAS, "out overlaps in");
+    return layout_transpose_launch(in, out, B, H, W, C, to_layout, dtype, (hipStream_t)stream);
+}
 
 int qpwc_device_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     if (!src || !dst) return fail(QPWC_E_NULL, "null pointer argument");
@@ -269,7 +282,7 @@ int qpwc_dwconv3x3_fwd(const void* const* src, const int* src_channels,
     if ((uintptr_t)out % es || (uintptr_t)weight % 4) return fail(QPWC_E_ALIGN, "pointer not element aligned");
     const size_t n_out = (size_t)B * H * W * C * es;
     for (int i = 0; i < n_src; ++i)
-        if (overlaps(out, n_out, src[i], (size_t)B * H * W * src_pixel_stride[i] * es))
+        if (overlaps(out, n_out, src[i], (((size_t)B * H * W - 1) * src_pixel_stride[i] + src_channels[i]) * es))
             return fail(QPWC_E_ALIAS, "out overlaps source %d", i);
     if ((int64_t)W * C > INT32_MAX) return fail(QPWC_E_SHAPE, "row too long");
     return dwconv3x3_launch(src, src_channels, src_pixel_stride, n_src, mish_on_load, weight, out, B,
@@ -291,7 +304,8 @@ int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
             return fail(QPWC_E_STRIDE, "source %d: %d channels at pixel stride %lld", i,
                         src_channels[i], (long long)src_pixel_stride[i]);
         if ((uintptr_t)src[i] % 4) return fail(QPWC_E_ALIGN, "source %d not 4-byte aligned", i);
-        if (overlaps(out, (size_t)B * H * W * F * 4, src[i], (size_t)B * H * W * src_pixel_stride[i] * 4))
+        if (overlaps(out, (size_t)B * H * W * F * 4, src[i],
+                     (((size_t)B * H * W - 1) * src_pixel_stride[i] + src_channels[i]) * 4))
             return fail(QPWC_E_ALIAS, "out overlaps source %d", i);
     }
     if ((uintptr_t)out % 16 || (uintptr_t)pw % 16 || (uintptr_t)bias % 16 || (uintptr_t)dw % 4)
@@ -320,7 +334,8 @@ int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels, con
             return fail(QPWC_E_ALIGN, "source %d: %d channels at stride %lld must be multiples of 4, 8-byte aligned",
                         i, src_channels[i], (long long)src_pixel_stride[i]);
         if ((uintptr_t)src[i] % 2) return fail(QPWC_E_ALIGN, "source %d not element aligned", i);
-        if (overlaps(out, (size_t)B * H * W * F * 2, src[i], (size_t)B * H * W * src_pixel_stride[i] * 2))
+        if (overlaps(out, (size_t)B * H * W * F * 2, src[i],
+                     (((size_t)B * H * W - 1) * src_pixel_stride[i] + src_channels[i]) * 2))
             return fail(QPWC_E_ALIAS, "out overlaps source %d", i);
         if ((int64_t)H * W * src_pixel_stride[i] > INT32_MAX) return fail(QPWC_E_SHAPE, "image too large");
     }
@@ -334,8 +349,10 @@ int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels, con
 int qpwc_flow_head_param_floats(void) { return flow_head_param_floats(); }
 
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W, float scale,
-                       int dtype, void* stream) {
+                       int dtype, int out_layout, void* stream) {
     if (!z || !params || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (out_layout != QPWC_NHWC && out_layout != QPWC_NCHW)
+        return fail(QPWC_E_LAYOUT, "Unsupported data format : %d", out_layout);
     if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
     const size_t es = esize(dtype);
     if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
@@ -343,7 +360,7 @@ int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int 
         return fail(QPWC_E_ALIGN, "z must be aligned to 4 elements, out to 2");
     if (overlaps(out, (size_t)B * H * W * 2 * es, z, (size_t)B * H * W * 16 * es))
         return fail(QPWC_E_ALIAS, "out overlaps z");
-    return flow_head_launch(z, params, out, B, H, W, scale, dtype, (hipStream_t)stream);
+    return flow_head_launch(z, params, out, B, H, W, scale, dtype, out_layout, (hipStream_t)stream);
 }
 
 int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int dtype, void* stream) {
@@ -388,32 +405,39 @@ int qpwc_split_frames_pad_fwd(const void* in, void* out, int B, int H, int W, in
 }
 
 int qpwc_upsample2x_flow_fwd(const void* in, void* out, int B, int h, int w, float scale, int dtype,
-                             void* stream) {
+                             int in_layout, int out_layout, void* stream) {
     if (!in || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if ((in_layout != QPWC_NHWC && in_layout != QPWC_NCHW) || (out_layout != QPWC_NHWC && out_layout != QPWC_NCHW))
+        return fail(QPWC_E_LAYOUT, "Unsupported data format : %d / %d", in_layout, out_layout);
     if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
     const size_t es = esize(dtype);
     if (B <= 0 || h <= 0 || w <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d h=%d w=%d", B, h, w);
     if ((uintptr_t)in % es || (uintptr_t)out % es) return fail(QPWC_E_ALIGN, "flow pointers must be element aligned");
     if (overlaps(out, (size_t)B * 4 * h * w * 2 * es, in, (size_t)B * h * w * 2 * es))
         return fail(QPWC_E_ALIAS, "out overlaps in");
-    return upsample2x_flow_launch(in, out, B, h, w, scale, dtype, (hipStream_t)stream);
+    return upsample2x_flow_launch(in, out, B, h, w, scale, dtype, in_layout, out_layout, (hipStream_t)stream);
 }
 
 int qpwc_epe_multi_workspace_floats(void) { return epe_multi_workspace_floats(); }
 
 int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
-                       int n_levels, void* out_means, void* workspace, void* stream) {
+                       const int64_t* plane_pixels, int n_levels, void* out_means, void* workspace,
+                       void* stream) {
     if (!y_true || !y_pred || !n_pixels || !out_means || !workspace)
         return fail(QPWC_E_NULL, "null pointer argument");
     if (n_levels < 1 || n_levels > 8) return fail(QPWC_E_SHAPE, "n_levels %d outside [1,8]", n_levels);
     for (int i = 0; i < n_levels; ++i) {
         if (!y_true[i] || !y_pred[i]) return fail(QPWC_E_NULL, "null flow pointer at level %d", i);
         if (n_pixels[i] <= 0) return fail(QPWC_E_SHAPE, "level %d has no pixels", i);
-        if ((uintptr_t)y_true[i] % 8 || (uintptr_t)y_pred[i] % 8)
-            return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte aligned");
+        const bool planar = plane_pixels && plane_pixels[i] > 0;
+        if (planar && n_pixels[i] % plane_pixels[i])
+            return fail(QPWC_E_SHAPE, "level %d: %lld pixels are not whole planes of %lld", i,
+                        (long long)n_pixels[i], (long long)plane_pixels[i]);
+        if ((uintptr_t)y_true[i] % (planar ? 4 : 8) || (uintptr_t)y_pred[i] % (planar ? 4 : 8))
+            return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte (pixels) / 4-byte (planes) aligned");
     }
-    return epe_multi_launch(y_true, y_pred, n_pixels, n_levels, (float*)out_means, (float*)workspace,
-                            (hipStream_t)stream);
+    return epe_multi_launch(y_true, y_pred, n_pixels, plane_pixels, n_levels, (float*)out_means,
+                            (float*)workspace, (hipStream_t)stream);
 }
 
 int qpwc_cost_volume_to_flow_fwd(const void* cvol, void* flow, int B, int H, int W, int D,
@@ -476,15 +500,16 @@ int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, v
 }
 
 int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,
-                             int H, int W, void* stream) {
+                             int H, int W, int layout, void* stream) {
     if (!pairs || !weight || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (layout != QPWC_NHWC && layout != QPWC_NCHW) return fail(QPWC_E_LAYOUT, "Unsupported data format : %d", layout);
     if (B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1))
         return fail(QPWC_E_SHAPE, "B=%d H=%d W=%d: H and W must be even and >= 2", B, H, W);
     if ((uintptr_t)pairs % 8 || (uintptr_t)weight % 4 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
         return fail(QPWC_E_ALIGN, "pairs must be 8-byte, bias and out 16-byte aligned");
     if (overlaps(out, (size_t)2 * B * (H / 2) * (W / 2) * 16 * 4, pairs, (size_t)B * H * W * 6 * 4))
         return fail(QPWC_E_ALIAS, "out overlaps pairs");
-    return first_conv_mish_launch(pairs, weight, bias, out, B, H, W, (hipStream_t)stream);
+    return first_conv_mish_launch(pairs, weight, bias, out, B, H, W, layout, (hipStream_t)stream);
 }
 
 int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __
                                                                  const float* __restrict__ weight,
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ out, int B, int H, int W,
-                                                                 int tiles_x, int tiles_y) {
+                                                                 int tiles_x, int tiles_y, int in_nchw) {
     __shared__ __attribute__((aligned(16))) float in_s[kFcIH * kFcIW * 6];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -439,6 +439,16 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __
     const int Ho = H / 2, Wo = W / 2;
     const float* xb = x + (int64_t)b * H * W * 6;
     // ---- stage the input patch: rows 2 Y0 .. + 16, columns 2 X0 .. + 32, 6 channels (8-byte pieces) ----
+    if (in_nchw) {   // (B,6,H,W) 'channels_first' input: six planes, lanes walk a row of a plane
+        for (int idx = tid; idx < 6 * kFcIH * kFcIW; idx += 256) {
+            const int c = idx / (kFcIH * kFcIW), r = idx - c * (kFcIH * kFcIW);
+            const int row = r / kFcIW, col = r - row * kFcIW;
+            const int gy = 2 * Y0 + row, gx = 2 * X0 + col;
+            float v = 0.f;
+            if (gy < H && gx < W) v = xb[((int64_t)c * H + gy) * W + gx];
+            in_s[r * 6 + c] = v;
+        }
+    } else
     for (int idx = tid; idx < kFcIH * kFcIW * 3; idx += 256) {
         const int row = idx / (kFcIW * 3), e = idx - row * (kFcIW * 3);   // e = float2 index inside the row
         const int gy = 2 * Y0 + row, gx = 2 * X0 + e / 3;
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __
 }
 
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
-                           hipStream_t s) {
+                           int layout, hipStream_t s) {
     const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + kEcTH - 1) / kEcTH;
     const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
     if (nblk > INT32_MAX) {
@@ -486,7 +496,8 @@ int first_conv_mish_launch(const void* x, const void* weight, const void* bias, 
         return QPWC_E_SHAPE;
     }
     hipLaunchKernelGGL(first_conv_mish_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const float*)x,
-                       (const float*)weight, (const float*)bias, (float*)out, B, H, W, tiles_x, tiles_y);
+                       (const float*)weight, (const float*)bias, (float*)out, B, H, W, tiles_x, tiles_y,
+                       layout == QPWC_NCHW ? 1 : 0);
     return check_launch("first_conv_mish_kernel");
 }
 

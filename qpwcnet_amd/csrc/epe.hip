@@ -71,6 +71,7 @@ struct EpeLevels {
     const float* a[kEpeMaxLevels];
     const float* b[kEpeMaxLevels];
     int64_t npix[kEpeMaxLevels];
+    int64_t plane[kEpeMaxLevels];   // 0: (B,H,W,2) pixels; > 0: (B,2,H,W) with H*W = plane
 };
 
 __global__ __launch_bounds__(kEpeThreads) void epe_multi_partial_kernel(EpeLevels lv,
@@ -82,9 +83,19 @@ __global__ __launch_bounds__(kEpeThreads) void epe_multi_partial_kernel(EpeLevel
     const int64_t n = lv.npix[l];
     float s = 0.0f;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane = lv.plane[l];
     // two pixels per 16-byte load, four loads of each array in flight (the finest level is 1 M pixels
     // for 65 k threads: one 8-byte load at a time made this pass latency bound)
-    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 == 0) {
+    if (plane > 0) {   // 'channels_first' flows: x and y planes, lanes walk the pixels of a plane
+        const float* af = lv.a[l];
+        const float* bf = lv.b[l];
+        for (int64_t i = tid; i < n; i += nthr) {
+            const int64_t img = i / plane, r = i - img * plane;
+            const int64_t o = img * 2 * plane + r;
+            const float dx = af[o] - bf[o], dy = af[o + plane] - bf[o + plane];
+            s += sqrtf(dx * dx + dy * dy);
+        }
+    } else if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 == 0) {
         const float4* a4 = reinterpret_cast<const float4*>(a);
         const float4* b4 = reinterpret_cast<const float4*>(b);
         const int64_t n2 = n / 2;
@@ -138,13 +149,14 @@ __global__ __launch_bounds__(kEpeThreads) void epe_multi_final_kernel(const floa
 
 int epe_multi_workspace_floats() { return kEpeMaxLevels * kEpeMultiBlocks; }
 
-int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, int n_levels,
-                     float* out, float* ws, hipStream_t s) {
+int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, const int64_t* plane,
+                     int n_levels, float* out, float* ws, hipStream_t s) {
     EpeLevels lv;
     for (int i = 0; i < kEpeMaxLevels; ++i) {
         lv.a[i] = i < n_levels ? (const float*)a[i] : nullptr;
         lv.b[i] = i < n_levels ? (const float*)b[i] : nullptr;
         lv.npix[i] = i < n_levels ? npix[i] : 0;
+        lv.plane[i] = (i < n_levels && plane) ? plane[i] : 0;
     }
     hipLaunchKernelGGL(epe_multi_partial_kernel, dim3(kEpeMultiBlocks, n_levels), dim3(kEpeThreads), 0, s,
                        lv, ws);

@@ -949,7 +949,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void flow_head_kernel(const T* __restrict__ z,
                                                            const float* __restrict__ params,
                                                            T* __restrict__ out, int H, int W,
-                                                           int tiles_x, int tiles_y, float scale) {
+                                                           int tiles_x, int tiles_y, float scale,
+                                                           int out_nchw) {
     constexpr int TW = kFhTile + 2;
     constexpr int NH = TW * TW;                                        // 324 halo pixels
     __shared__ __attribute__((aligned(16))) float hs[(NH + 12) * kFhC];  // 21 groups of 16 pixels
@@ -1030,9 +1031,15 @@ __global__ __launch_bounds__(256, 2) void flow_head_kernel(const T* __restrict__
         fx += __shfl_xor(fx, 32); fy += __shfl_xor(fy, 32);
         const int gx = x0 + n, gy = y0 + ry;
         if (g == 0 && gx < W && gy < H) {
-            T* o = out + ((int64_t)(b * H + gy) * W + gx) * 2;
-            st(o, scale * fx);
-            st(o + 1, scale * fy);
+            if (out_nchw) {   // (B,2,H,W): the model's 'channels_first' output, no transposition launch
+                T* o = out + ((int64_t)(b * 2) * H + gy) * W + gx;
+                st(o, scale * fx);
+                st(o + (int64_t)H * W, scale * fy);
+            } else {
+                T* o = out + ((int64_t)(b * H + gy) * W + gx) * 2;
+                st(o, scale * fx);
+                st(o + 1, scale * fy);
+            }
         }
     }
 }
@@ -1121,7 +1128,7 @@ int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dty
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restrict__ in,
                                                               T* __restrict__ out, int B, int h,
-                                                              int w, float scale) {
+                                                              int w, float scale, int in_nchw, int out_nchw) {
     const int H = 2 * h, W = 2 * w;
     const int64_t total = (int64_t)B * H * W;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1135,6 +1142,10 @@ __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restric
         const float ly = sy - y0, lx = sx - x0;
         const T* p = in + (int64_t)b * h * w * 2;
         auto px = [&](int yy, int xx) {
+            if (in_nchw) {   // (B,2,h,w): what flow_head writes for a 'channels_first' model
+                const T* q = p + (int64_t)yy * w + xx;
+                return make_float2(ld(q), ld(q + (int64_t)h * w));
+            }
             const T* q = p + ((int64_t)yy * w + xx) * 2;
             return make_float2(ld(q), ld(q + 1));
         };
@@ -1143,22 +1154,29 @@ __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restric
         float2 r;
         r.x = scale * (w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x);
         r.y = scale * (w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y);
-        st(out + 2 * idx, r.x);
-        st(out + 2 * idx + 1, r.y);
+        if (out_nchw) {
+            T* o = out + ((int64_t)(b * 2) * H + y) * W + x;
+            st(o, r.x);
+            st(o + (int64_t)H * W, r.y);
+        } else {
+            st(out + 2 * idx, r.x);
+            st(out + 2 * idx + 1, r.y);
+        }
     }
 }
 
 int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, int dtype,
-                           hipStream_t s) {
+                           int in_layout, int out_layout, hipStream_t s) {
+    const int in_nchw = in_layout == QPWC_NCHW, out_nchw = out_layout == QPWC_NCHW;
     const int64_t total = (int64_t)B * 4 * h * w;
     const int64_t want = (total + 255) / 256;
     const dim3 grid((unsigned)(want < 8192 ? want : 8192));
     if (dtype == QPWC_F32)
         hipLaunchKernelGGL(upsample2x_flow_kernel<float>, grid, dim3(256), 0, s, (const float*)in,
-                           (float*)out, B, h, w, scale);
+                           (float*)out, B, h, w, scale, in_nchw, out_nchw);
     else
         hipLaunchKernelGGL(upsample2x_flow_kernel<__half>, grid, dim3(256), 0, s, (const __half*)in,
-                           (__half*)out, B, h, w, scale);
+                           (__half*)out, B, h, w, scale, in_nchw, out_nchw);
     return check_launch("upsample2x_flow_kernel");
 }
 
@@ -1203,15 +1221,16 @@ int split_frames_pad_launch(const void* in, void* out, int B, int H, int W, int 
 int flow_head_param_floats() { return kFhParams; }
 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
-                     int dtype, hipStream_t s) {
+                     int dtype, int out_layout, hipStream_t s) {
+    const int out_nchw = out_layout == QPWC_NCHW;
     const int tiles_x = (W + kFhTile - 1) / kFhTile, tiles_y = (H + kFhTile - 1) / kFhTile;
     const dim3 grid((unsigned)(tiles_x * tiles_y * B));
     if (dtype == QPWC_F32)
         hipLaunchKernelGGL(flow_head_kernel<float>, grid, dim3(256), 0, s, (const float*)z,
-                           (const float*)params, (float*)out, H, W, tiles_x, tiles_y, scale);
+                           (const float*)params, (float*)out, H, W, tiles_x, tiles_y, scale, out_nchw);
     else
         hipLaunchKernelGGL(flow_head_kernel<__half>, grid, dim3(256), 0, s, (const __half*)z,
-                           (const float*)params, (__half*)out, H, W, tiles_x, tiles_y, scale);
+                           (const float*)params, (__half*)out, H, W, tiles_x, tiles_y, scale, out_nchw);
     return check_launch("flow_head_kernel");
 }
 

@@ -26,8 +26,8 @@ def multiscale_ground_truth(flow_gt, shapes, data_format=CHANNELS_LAST):
 def per_level_epe(flows_true, flows_pred, data_format=CHANNELS_LAST, out=None):
     """-> float32 tensor [n_levels] on the flows' device (HIP reduction kernel); written into ``out``
     when given (the all-gather payload, see qpwcnet_amd.dist.EpeGather.payload_view)."""
-    if data_format == CHANNELS_LAST and len(flows_true) <= 8:
-        return ops.epe_multi(flows_true, flows_pred, out=out)  # all levels in two launches
+    if len(flows_true) <= 8:
+        return ops.epe_multi(flows_true, flows_pred, out=out, data_format=data_format)  # two launches
     res = torch.stack([ops.epe(t, p.float(), data_format) for t, p in zip(flows_true, flows_pred)])
     if out is not None:
         out.copy_(res)

@@ -310,19 +310,23 @@ class DownConv(_Weighted):
         return (self.hip_conv and y_nchw.dtype == torch.float32 and y_nchw.shape[1] in (16, 32, 64, 128, 256) and
                 _hip_act_ok(y_nchw, self.data_format))
 
-    def first_layer(self, pairs):
-        """enc.0.conv_a on the raw (B,H,W,6) pair: split, frame stacking, 'SAME' padding, stride-2 conv,
-        bias and Mish in one HIP launch -> (2B, H/2, W/2, 16), or None when that kernel does not apply."""
+    def first_layer(self, pairs, pairs_format=None):
+        """enc.0.conv_a on the raw (B,H,W,6) pair -- (B,6,H,W) for pairs_format 'channels_first' --: split,
+        frame stacking, 'SAME' padding, stride-2 conv, bias and Mish in one HIP launch -> (2B, H/2, W/2, 16)
+        channels-last, or None when that kernel does not apply."""
         w = self.p("conv_a.weight")
+        pf = self.data_format if pairs_format is None else pairs_format
+        hh, ww, cc = (pairs.shape[2], pairs.shape[3], pairs.shape[1]) if pf == CHANNELS_FIRST else \
+            (pairs.shape[1], pairs.shape[2], pairs.shape[3])
         if not (self.hip_conv and self.data_format == CHANNELS_LAST and pairs.is_cuda and
                 pairs.dtype == torch.float32 and tuple(w.shape) == (16, 3, 3, 3) and
-                pairs.shape[1] % 2 == 0 and pairs.shape[2] % 2 == 0 and pairs.shape[3] == 6):
+                hh % 2 == 0 and ww % 2 == 0 and cc == 6):
             return None
         key = self.prefix + "#taps_a"
         t = self.params.get(key)
         if t is None:
             t = self.params[key] = ops.first_conv_taps(w)
-        return ops.first_conv_mish(pairs.contiguous(), t, self.p32("conv_a.bias"))
+        return ops.first_conv_mish(pairs.contiguous(), t, self.p32("conv_a.bias"), pf)
 
     def _taps(self):
         key = self.prefix + "#taps"
@@ -449,7 +453,7 @@ class OptFlow(_Weighted):
                 z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1),
                                 self._pw_t84 if first84 else self._pw_t[i]).view(B, H, W, -1)
                 z_act = False
-        return ops.flow_head(z, self._head, scale)
+        return ops.flow_head(z, self._head, scale, getattr(self, "out_format", CHANNELS_LAST))
 
     def __call__(self, inputs):
         shape = parse_image_shape(inputs, self.data_format)

@@ -115,6 +115,34 @@ def _empty_like_layout(ref, dims, channels, layout, as_nchw_view):
     return buf, buf
 
 
+def layout_transpose(x, to_format):
+    """Dense (B,C,H,W) -> dense (B,H,W,C) for to_format 'channels_last', the reverse for
+    'channels_first' (qpwc_layout_transpose_fwd): how a 'channels_first' tensor crosses the boundary
+    of the channels-last kernels (the reference transposes in and out the same way, layers.py:179-183)."""
+    _check_tensor("x", x)
+    get_axis(to_format)
+    x = x.contiguous()
+    if to_format == CHANNELS_LAST:
+        B, C, H, W = x.shape
+        out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+        code = _hip.NHWC
+    else:
+        B, H, W, C = x.shape
+        out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
+        code = _hip.NCHW
+    with torch.cuda.device(x.device), _timed("layout_transpose", (B, H, W, C)):
+        rc = _hip.lib().qpwc_layout_transpose_fwd(x.data_ptr(), out.data_ptr(), B, H, W, C, code,
+                                                   _DTYPES[x.dtype], _stream(x))
+    _hip.check(rc)
+    return out
+
+
+def _nchw_fast_path(C, search_range=4):
+    """Dense NCHW operands of the hot-path layers go through a transposition to the channels-last
+    kernels when those have a vector path for the shape (else: the generic any-layout kernels)."""
+    return C % 4 == 0 and search_range == 4
+
+
 def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST, lrelu_slope=0.1):
     """CostVolume / CostVolumeV2 forward (reference: qpwcnet/core/layers.py:72-100,128-132)."""
     _check_tensor("prv", prv)
@@ -131,9 +159,12 @@ def cost_volume(prv, nxt, search_range=4, data_format=CHANNELS_LAST, lrelu_slope
         layout, as_view = (_hip.NCHW if data_format == CHANNELS_FIRST else _hip.NHWC), False
     B, H, W, C = dims
     d = 2 * int(search_range) + 1
+    if layout == _hip.NCHW and _nchw_fast_path(C, int(search_range)):
+        # dense (B,C,H,W): transpose in, matrix-core / LDS-tiled channels-last kernel, transpose out
+        out_l = cost_volume(layout_transpose(p, CHANNELS_LAST), layout_transpose(n, CHANNELS_LAST), search_range,
+                            CHANNELS_LAST, lrelu_slope)
+        return layout_transpose(out_l, CHANNELS_FIRST)
     buf, out = _empty_like_layout(p, dims, d * d, layout, as_view)
-    if _TIMER is not None and _TIMER.capture == ("cost_volume",) + tuple(dims):
-        _TIMER.captured = (p, n, d * d)
     with torch.cuda.device(p.device), _timed("cost_volume", dims):
         rc = _hip.lib().qpwc_cost_volume_fwd(
             p.data_ptr(), n.data_ptr(), buf.data_ptr(), B, H, W, C, int(search_range), layout,
@@ -208,6 +239,10 @@ def warp(img, flo, mode="clamp", data_format=CHANNELS_LAST):
         raise ValueError("unknown warp mode '{}'".format(mode))
     i, layout, dims, as_view = _physical(img, data_format)
     B, H, W, C = dims
+    if layout == _hip.NCHW and C % 4 == 0 and (H >= 2 and W >= 2 or mode == "tfwarp"):
+        # dense (B,C,H,W): the 16-byte gather kernel on a channels-last copy (flow: 2 channels, permuted)
+        out_l = warp(layout_transpose(i, CHANNELS_LAST), flo.permute(0, 2, 3, 1), mode, CHANNELS_LAST)
+        return layout_transpose(out_l, CHANNELS_FIRST)
     f, mask = _flow_physical(flo, dims, data_format, layout)
     buf, out = _empty_like_layout(i, dims, C, layout, as_view)
     with torch.cuda.device(i.device), _timed("warp_" + mode, dims):
@@ -234,8 +269,6 @@ def cost_volume_into(prv, nxt, out, channel_offset=0, search_range=4, lrelu_slop
     B, H, W, C = prv.shape
     if out.shape[:3] != prv.shape[:3]:
         raise ValueError("out must be (B,H,W,Ctot) with the image's B,H,W")
-    if flo is None and _TIMER is not None and _TIMER.capture == ("cost_volume", B, H, W, C):
-        _TIMER.captured = (prv, nxt, out.shape[3])   # inputs + pixel stride of the step's own launch
     L = _hip.lib()
     with torch.cuda.device(prv.device), \
             _timed("cost_volume" if flo is None else "warp_cost_volume", (B, H, W, C)):
@@ -312,9 +345,10 @@ def dwconv3x3(sources, weight, mish_on_load=False):
     return out
 
 
-def flow_head(z, params, scale):
+def flow_head(z, params, scale, out_format=CHANNELS_LAST):
     """Tail of OptFlow (non_layers.py:238-254, 268-273) on the pre-activation 16-channel
-    tensor z (B,H,W,16): scale * conv3x3(BN(Mish(W1 Mish(z) + b1))) -> (B,H,W,2).
+    tensor z (B,H,W,16): scale * conv3x3(BN(Mish(W1 Mish(z) + b1))) -> (B,H,W,2), or (B,2,H,W) for
+    out_format 'channels_first' (a channels_first model's output, written by the kernel itself).
     params: packed fp32 vector, see include/qpwc.h / non_layers.pack_flow_head."""
     _check_tensor("z", z)
     if z.shape[3] != 16 or not z.is_contiguous():
@@ -325,10 +359,12 @@ def flow_head(z, params, scale):
         raise ValueError("params must be a dense fp32 device vector of {} floats".format(
             L.qpwc_flow_head_param_floats()))
     B, H, W, _ = z.shape
-    out = torch.empty((B, H, W, 2), dtype=z.dtype, device=z.device)
+    get_axis(out_format)
+    cf = out_format == CHANNELS_FIRST
+    out = torch.empty((B, 2, H, W) if cf else (B, H, W, 2), dtype=z.dtype, device=z.device)
     with torch.cuda.device(z.device), _timed("flow_head", (B, H, W, 16)):
         rc = L.qpwc_flow_head_fwd(z.data_ptr(), params.data_ptr(), out.data_ptr(), B, H, W,
-                                  float(scale), _DTYPES[z.dtype], _stream(z))
+                                  float(scale), _DTYPES[z.dtype], _hip.NCHW if cf else _hip.NHWC, _stream(z))
     _hip.check(rc)
     return out
 
@@ -351,18 +387,27 @@ def bias_mish_(x_nhwc, bias=None):
     return x_nhwc
 
 
-def upsample2x_flow(flo, scale=1.0):
-    """scale * bilinear x2 upsampling of a channels-last fp32 flow (B,h,w,2) -- the reference's
-    Upsample functor (non_layers.py:183-193) as used on flows (pwcnet.py:55,60)."""
+def upsample2x_flow(flo, scale=1.0, in_format=CHANNELS_LAST, out_format=CHANNELS_LAST):
+    """scale * bilinear x2 upsampling of a flow (B,h,w,2) [(B,2,h,w) for in_format 'channels_first'] --
+    the reference's Upsample functor (non_layers.py:183-193) as used on flows (pwcnet.py:55,60);
+    out (B,2h,2w,2) or (B,2,2h,2w) by out_format."""
     _check_tensor("flo", flo)
-    if flo.shape[3] != 2:
-        raise ValueError("upsample2x_flow takes a (B,h,w,2) tensor")
+    get_axis(in_format)
+    get_axis(out_format)
+    if flo.shape[1 if in_format == CHANNELS_FIRST else 3] != 2:
+        raise ValueError("upsample2x_flow takes a 2-channel flow, got shape {}".format(tuple(flo.shape)))
     f = flo.contiguous()
-    B, h, w, _ = f.shape
-    out = torch.empty((B, 2 * h, 2 * w, 2), dtype=f.dtype, device=f.device)
+    if in_format == CHANNELS_FIRST:
+        B, _, h, w = f.shape
+    else:
+        B, h, w, _ = f.shape
+    ocf = out_format == CHANNELS_FIRST
+    out = torch.empty((B, 2, 2 * h, 2 * w) if ocf else (B, 2 * h, 2 * w, 2), dtype=f.dtype, device=f.device)
     with torch.cuda.device(f.device), _timed("upsample2x_flow", (B, h, w, 2)):
         rc = _hip.lib().qpwc_upsample2x_flow_fwd(f.data_ptr(), out.data_ptr(), B, h, w, float(scale),
-                                                  _DTYPES[f.dtype], _stream(f))
+                                                  _DTYPES[f.dtype],
+                                                  _hip.NCHW if in_format == CHANNELS_FIRST else _hip.NHWC,
+                                                  _hip.NCHW if ocf else _hip.NHWC, _stream(f))
     _hip.check(rc)
     return out
 
@@ -408,26 +453,29 @@ def occlusion_map(flow, data_format=CHANNELS_LAST):
     return out
 
 
-def epe_multi(flows_true, flows_pred, out=None):
-    """Per-level EPE of up to 8 channels-last fp32 flow pairs in two launches
-    (FlowMseLoss, qpwcnet/train/loss.py:56-67) -> float32 tensor [n_levels].
+def epe_multi(flows_true, flows_pred, out=None, data_format=CHANNELS_LAST):
+    """Per-level EPE of up to 8 fp32 flow pairs ((B,h,w,2), or (B,2,h,w) for 'channels_first') in two
+    launches (FlowMseLoss, qpwcnet/train/loss.py:56-67) -> float32 tensor [n_levels].
     ``out``: dense fp32 device vector [n_levels] to write into (e.g. the all-gather payload of
     qpwcnet_amd.dist.EpeGather, so that no copy stands between the reduction and the collective)."""
     import ctypes
     n = len(flows_true)
     if n != len(flows_pred) or not 1 <= n <= 8:
         raise ValueError("epe_multi takes 1..8 (true, pred) pairs")
-    keep, pa, pb, npix = [], [], [], []
+    cf = data_format == CHANNELS_FIRST
+    get_axis(data_format)
+    keep, pa, pb, npix, plane = [], [], [], [], []
     for i, (a, b) in enumerate(zip(flows_true, flows_pred)):
         _check_tensor("y_true[%d]" % i, a)
         _check_tensor("y_pred[%d]" % i, b)
-        if a.shape != b.shape or a.shape[3] != 2:
+        if a.shape != b.shape or a.shape[1 if cf else 3] != 2:
             raise ValueError("level {}: shapes {} / {}".format(i, tuple(a.shape), tuple(b.shape)))
         a, b = a.float().contiguous(), b.float().contiguous()
         keep += [a, b]
         pa.append(a.data_ptr())
         pb.append(b.data_ptr())
         npix.append(a.numel() // 2)
+        plane.append(a.shape[2] * a.shape[3] if cf else 0)
     dev = keep[0].device
     L = _hip.lib()
     ws = torch.empty(L.qpwc_epe_multi_workspace_floats(), dtype=torch.float32, device=dev)
@@ -437,8 +485,8 @@ def epe_multi(flows_true, flows_pred, out=None):
         raise ValueError("out must be a dense fp32 vector of {} elements on {}".format(n, dev))
     with torch.cuda.device(dev):
         rc = L.qpwc_epe_multi_fwd((ctypes.c_void_p * n)(*pa), (ctypes.c_void_p * n)(*pb),
-                                  (ctypes.c_int64 * n)(*npix), n, out.data_ptr(), ws.data_ptr(),
-                                  _stream(out))
+                                  (ctypes.c_int64 * n)(*npix), (ctypes.c_int64 * n)(*plane), n,
+                                  out.data_ptr(), ws.data_ptr(), _stream(out))
     _hip.check(rc)
     return out
 
@@ -556,21 +604,27 @@ def first_conv_taps(weight):
     return out
 
 
-def first_conv_mish(pairs, taps, bias):
+def first_conv_mish(pairs, taps, bias, data_format=CHANNELS_LAST):
     """Split(2) + frame stacking + Conv2D(3->16, 3x3, stride 2, 'same') + bias + Mish of the first
-    encoder layer (pwcnet.py:229, non_layers.py:402-409) on the raw (B,H,W,6) fp32 input, H and W even
-    -> (2B, H/2, W/2, 16).  taps from first_conv_taps()."""
+    encoder layer (pwcnet.py:229, non_layers.py:402-409) on the raw (B,H,W,6) fp32 input -- or (B,6,H,W)
+    for 'channels_first' --, H and W even -> (2B, H/2, W/2, 16) channels-last.  taps from first_conv_taps()."""
     _check_tensor("pairs", pairs)
-    if pairs.shape[3] != 6 or pairs.dtype != torch.float32 or not pairs.is_contiguous():
-        raise ValueError("pairs must be a dense fp32 (B,H,W,6) tensor")
-    B, H, W, _ = pairs.shape
+    cf = data_format == CHANNELS_FIRST
+    get_axis(data_format)
+    if pairs.shape[1 if cf else 3] != 6 or pairs.dtype != torch.float32 or not pairs.is_contiguous():
+        raise ValueError("pairs must be a dense fp32 (B,H,W,6) / (B,6,H,W) tensor")
+    if cf:
+        B, _, H, W = pairs.shape
+    else:
+        B, H, W, _ = pairs.shape
     if tuple(taps.shape) != (9, 16, 4) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
             bias.numel() != 16 or bias.dtype != torch.float32:
         raise ValueError("taps must be fp32 (9,16,4), bias fp32 (16)")
     out = torch.empty((2 * B, H // 2, W // 2, 16), dtype=torch.float32, device=pairs.device)
     with torch.cuda.device(out.device), _timed("first_conv_mish", (B, H, W, 6)):
         rc = _hip.lib().qpwc_first_conv_mish_fwd(pairs.data_ptr(), taps.data_ptr(), bias.data_ptr(),
-                                                 out.data_ptr(), B, H, W, _stream(out))
+                                                 out.data_ptr(), B, H, W, _hip.NCHW if cf else _hip.NHWC,
+                                                 _stream(out))
     _hip.check(rc)
     return out
 

@@ -93,7 +93,7 @@ class QpwcNet:
 
     def __init__(self, weights, train=True, input_shape=(256, 512), data_format=None,
                  use_tfa=True, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True,
-                 batch_frames=True, overlap_streams=True):
+                 batch_frames=True, overlap_streams=True, internal_channels_last=True):
         self.data_format = image_data_format() if data_format is None else data_format
         self.axis = get_axis(self.data_format)
         self.train = train
@@ -103,13 +103,19 @@ class QpwcNet:
         self.input_shape = tuple(input_shape)
         self.device = torch.device(device)
         self.dtype = dtype
+        # 'channels_first' (the reference's inference default, app/optical_flow/test_infer.py:52) on a HIP
+        # device: inputs and outputs are (B,C,H,W), everything in between runs on the channels-last kernels.
+        # The first encoder kernel reads the six input planes itself, every flow_head writes its (B,2,h,w)
+        # output itself and the Upsample kernel reads / writes planes, so no transposition launch is added.
+        self._df = CHANNELS_LAST if (self.data_format == CHANNELS_FIRST and self.batch_frames and hip_optflow and
+                                     internal_channels_last and self.device.type == "cuda") else self.data_format
         self.params = {}
         for k, v in weights.items():
             t = torch.as_tensor(np.asarray(v)).to(self.device, dtype)
-            if t.dim() == 4 and self.data_format == CHANNELS_LAST:
+            if t.dim() == 4 and self._df == CHANNELS_LAST:
                 t = t.contiguous(memory_format=torch.channels_last)
             self.params[k] = t
-        df = self.data_format
+        df = self._df
         self.split = Split(2, axis=self.axis, data_format=df)
         self.enc = [DownConv(self.params, "enc.{}.".format(i), data_format=df)
                     for i in range(len(ENC_FILTERS))]
@@ -119,48 +125,52 @@ class QpwcNet:
         self.upflows = [UpFlow(self.params, "upflow.{}.".format(i), use_tfa=use_tfa, fused=fused,
                                hip_optflow=hip_optflow, data_format=df)
                         for i in range(len(DEC_FILTERS))]
+        if self._df != self.data_format:
+            for blk in [self.flow] + self.upflows:
+                blk.flow.out_format = self.data_format   # flow_head writes the (B,2,h,w) output itself
+
+    def _up(self, flo, last=False):
+        """Upsample(scale=2.0) between levels (pwcnet.py:55,60).  A channels_first model on the
+        channels-last kernels: the flow comes in the declared layout (flow_head wrote it so), the
+        next level wants it channels-last, the last one is an output again."""
+        if self._df != self.data_format and flo.is_cuda and flo.shape[1] == 2:
+            return ops.upsample2x_flow(flo, 2.0, in_format=self.data_format,
+                                       out_format=self.data_format if last else self._df)
+        return Upsample(scale=2.0, data_format=self.data_format)(flo)
 
     def __call__(self, inputs):
         exp = (self.input_shape + (6,)) if self.data_format == CHANNELS_LAST \
             else ((6,) + self.input_shape)
         if tuple(inputs.shape[1:]) != exp:
             raise ValueError("expected input shape (B,)+{}, got {}".format(exp, tuple(inputs.shape)))
-        img_prv, img_nxt = self.split(inputs)
         if self.batch_frames:
             nb = inputs.shape[0]
-            encs = self._encode_stacked(inputs, img_prv, img_nxt)
-            f = encs[-1]
-            if self.overlap_streams and inputs.is_cuda:
-                return self._forward_two_streams(encs, nb)
-            decs, i = [], -2
-            for l in self.dec:
-                f = l.cat_skip(f, encs[i])
-                i -= 1
-                decs.append(f)
-            encs_prv, encs_nxt = [e[:nb] for e in encs], [e[nb:] for e in encs]
-            decs_prv, decs_nxt = [d[:nb] for d in decs], [d[nb:] for d in decs]
-        else:
-            encs_prv, encs_nxt = encoder(self.enc, img_prv, img_nxt, True)
-            decs_prv, decs_nxt = decoder(self.dec, encs_prv, encs_nxt, self.axis, True)
+            encs = self._encode_stacked(inputs)
+            return self._forward_stacked(encs, nb, self.overlap_streams and inputs.is_cuda)
+        img_prv, img_nxt = self.split(inputs)
+        encs_prv, encs_nxt = encoder(self.enc, img_prv, img_nxt, True)
+        decs_prv, decs_nxt = decoder(self.dec, encs_prv, encs_nxt, self.axis, True)
         outs = flower(self.flow, self.upflows, encs_prv[-1], encs_nxt[-1], decs_prv, decs_nxt,
                       self.data_format, output_multiscale=self.train)
         return outs if self.train else outs[0]
 
-    def _encode_stacked(self, inputs, img_prv, img_nxt):
+    def _encode_stacked(self, inputs):
         """The encoder/decoder weights are shared by both frames (pwcnet.py:145-162, 179-206): run
         the encoder once on the 2B stacked frames [prv; nxt] -> [frames, enc_0 .. enc_4]."""
         h, w = self.input_shape
-        first = self.enc[0].first_layer(inputs)
+        first = self.enc[0].first_layer(inputs, self.data_format)
+        if first is None and self._df != self.data_format:
+            inputs = ops.layout_transpose(inputs, self._df)      # (fp16 storage: no planar first-layer kernel)
         if first is not None:
             # the frames themselves (entry 0 of the reference's feature lists) are not used downstream
             f, padded = inputs, None
-        elif (self.data_format == CHANNELS_LAST and inputs.is_cuda and h % 2 == 0 and w % 2 == 0 and
+        elif (self._df == CHANNELS_LAST and inputs.is_cuda and h % 2 == 0 and w % 2 == 0 and
                 inputs.dtype in (torch.float32, torch.float16)):
             # split + stack + 'SAME' padding of the first stride-2 conv in one pass
             padded = ops.split_frames_pad(inputs, 1, 1)
             f = padded[:, :h, :w, :]
         else:
-            f, padded = torch.cat([img_prv, img_nxt], dim=0), None
+            f, padded = torch.cat(list(self.split(inputs)), dim=0), None
         encs = [f]
         for li, l in enumerate(self.enc):
             # the activation epilogue of level li lays down the 'SAME' padding level li+1 needs
@@ -168,6 +178,23 @@ class QpwcNet:
                                          after_a=first if li == 0 else None)
             encs.append(f)
         return encs
+
+    def _forward_stacked(self, encs, nb, overlap):
+        """Decoder + flow chain on the stacked encoder outputs.  overlap: the two-stream form."""
+        if overlap:
+            return self._forward_two_streams(encs, nb)
+        f, decs, i = encs[-1], [], -2
+        for l in self.dec:
+            f = l.cat_skip(f, encs[i])
+            i -= 1
+            decs.append(f)
+        flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
+        flos = [flo]
+        for i, upflow in enumerate(self.upflows):
+            flo = upflow((decs[i][:nb], decs[i][nb:], self._up(flo)))
+            flos.append(flo)
+        flos.append(self._up(flo, last=True))
+        return flos if self.train else flos[-1]
 
     def _forward_two_streams(self, encs, nb):
         """Decoder chain on a side stream, flow chain on the caller's stream: the coarse
@@ -206,11 +233,11 @@ class QpwcNet:
         flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
         flos = [flo]
         for i, upflow in enumerate(self.upflows):
-            flo_u = Upsample(scale=2.0, data_format=self.data_format)(flo)
+            flo_u = self._up(flo)
             main.wait_event(ready[i])
             flo = upflow((decs[i][:nb], decs[i][nb:], flo_u))
             flos.append(flo)
-        flos.append(Upsample(scale=2.0, data_format=self.data_format)(flo))
+        flos.append(self._up(flo, last=True))
         main.wait_stream(side)              # join before anything is freed or returned
         return flos if self.train else flos[-1]
 
@@ -271,7 +298,7 @@ class QpwcInterpolator(QpwcNet):
                  batch_directions=True):
         super().__init__(weights, train=True, input_shape=input_shape, data_format=data_format,
                          use_tfa=use_tfa, device=device, dtype=dtype, hip_optflow=hip_optflow,
-                         batch_frames=True, overlap_streams=False)
+                         batch_frames=True, overlap_streams=False, internal_channels_last=False)
         df = self.data_format
         self.output_multiscale = bool(output_multiscale)
         self.batch_directions = bool(batch_directions)
@@ -288,7 +315,7 @@ class QpwcInterpolator(QpwcNet):
         img_prv, img_nxt = self.split(inputs)
         nb = inputs.shape[0]
         # shared encoder/decoder weights: both frames as one batch of 2B (as in QpwcNet)
-        encs = self._encode_stacked(inputs, img_prv, img_nxt)
+        encs = self._encode_stacked(inputs)
         f = encs[-1]
         decs, i = [], -2
         for l in self.dec:
