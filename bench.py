@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 
 from qpwcnet_amd import _hip  # noqa: E402
 from qpwcnet_amd import dist as qdist  # noqa: E402
-from qpwcnet_amd import metrics, ops, synth  # noqa: E402
+from qpwcnet_amd import metrics, non_layers, ops, synth  # noqa: E402
 from qpwcnet_amd.pwcnet import GraphedForward, build_flower  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is what its float4 copy reaches
@@ -288,7 +288,7 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
 
     # -- cost volume L4: the step's own launch shape (84-float pixels where the fused first OptFlow layer
     # reads them), random inputs, 50 back-to-back launches per round
-    fused4 = bool(getattr(up4, "fused", False))
+    fused4 = bool(up4.fused) and non_layers.fused_front_end_applies(prv, flo)
     cv_ms = replay_launches(lambda: ops.cost_volume_into(prv, nxt, cbuf, 0))
     sym_by_level = {"L4": cv_ms}
     for lv in (3, 2, 1, 0):
@@ -466,7 +466,10 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
             "hipgraph": graphs is not None,
             "epe_payload": ("written by the captured EPE reduction (two graphs, one pool)" if graphs is not None
                             and in_place else ("copied per step" if gather.collective else "single process")),
-            "fused_upflow": [bool(u.fused) for u in model.upflows],
+            # levels L1..L4 whose UpFlow runs WarpV2 + cost volume as one launch
+            "fused_upflow": [bool(u.fused) and tdtype == torch.float32 and
+                             B * (((hw[0] >> (4 - i)) + 7) // 8) * (((hw[1] >> (4 - i)) + 7) // 8) >= 256
+                             for i, u in enumerate(model.upflows)],
             "hip_optflow": True,
             "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",
         },

@@ -145,7 +145,7 @@ static int cost_volume_checked(const void* prv, const void* nxt, const void* flo
         return fail(QPWC_E_ALIAS, "out overlaps an input");
     char* o = (char*)out + (size_t)off * es;
     // 84-float pixels holding the 81 channels at offset 0: the 3 pad channels are written as zeros
-    const bool pad84 = strided && !fuse && r == 4 && ops == 84 && off == 0;
+    const bool pad84 = strided && r == 4 && ops == 84 && off == 0;
     return cost_volume_launch(prv, nxt, flo, o, B, H, W, C, r, layout, dtype, ops, slope, fuse, pad84,
                               (hipStream_t)stream);
 }

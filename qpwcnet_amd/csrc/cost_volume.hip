@@ -276,8 +276,8 @@ static int cost_volume_impl(const T* prv, const T* nxt, const float* flo, T* out
     return check_launch("cost_volume_generic_kernel");
 }
 
-int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, int H, int W, int C,
-                            int dtype, int64_t ops, float slope, int pad84, bool* pads_written,
+int cost_volume_mfma_launch(const void* prv, const void* nxt, const void* flo, void* out, int B, int H, int W,
+                            int C, int dtype, int64_t ops, float slope, int pad84, bool* pads_written,
                             hipStream_t s);
 
 // channels 81..83 of an 84-float pixel := 0 (see cost_volume_launch, pad84)
@@ -301,10 +301,10 @@ int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* 
         else
             hipLaunchKernelGGL(zero_pads_kernel<__half>, dim3(grid), dim3(256), 0, s, (__half*)out, npx);
     };
-    if (!fuse && layout == QPWC_NHWC && r == 4) {
+    if (layout == QPWC_NHWC && r == 4) {
         bool pads_written = false;
-        const int rc = cost_volume_mfma_launch(prv, nxt, out, B, H, W, C, dtype, ops, slope, pad84 ? 1 : 0,
-                                               &pads_written, s);
+        const int rc = cost_volume_mfma_launch(prv, nxt, fuse ? flo : nullptr, out, B, H, W, C, dtype, ops, slope,
+                                               pad84 ? 1 : 0, &pads_written, s);
         if (rc != 1) {  // 1 = shape not eligible for the matrix-core path
             if (rc == QPWC_OK && pad84 && !pads_written) zero_pads();
             return rc;

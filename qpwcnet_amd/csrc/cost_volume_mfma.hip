@@ -448,9 +448,24 @@ constexpr int kRegBlocks = 20;                       // 16 nxt + 4 prv
 constexpr int kRegStageBytes = kRegBlocks * 2048;    // 32 channels fp32 per step
 constexpr int kRegLdsBytes = kRegStageBytes > 4 * kFrameFloats * 4 ? kRegStageBytes : 4 * kFrameFloats * 4;
 
-__global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
-    const float* __restrict__ prv, const float* __restrict__ nxt, float* __restrict__ out, int H, int W,
-    int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c, int pad84) {
+//
+// WARP = true is the fused UpFlow front end (qpwcnet/core/non_layers.py:377-380: nxt_w = WarpV2(nxt, flo);
+// cost = cv(prv, nxt_w)): the staging step of a nxt piece gathers the four corner chunks of its pixel's
+// bilinear sample (tfa dense_image_warp, clamp-to-border: taps_clamp / blend of common.h, the very code of
+// warp.hip, every multiply and add rounded separately) and writes the blended chunk into the same swizzled
+// LDS slot -- from there on the kernel is the unfused one, so the result equals warp -> cost volume bit
+// for bit while nxt_w never exists in memory.  Pixels of the 16 x 16 neighbourhood outside the image are the
+// ZeroPadding2D of the WARPED image: zero, not sampled.  A lane computes the taps of ONE of its eight
+// pieces (the eight lanes of a pixel would all compute the same ones) and the group shares them through
+// the 1 KB of the staging area that only its own wave writes later.
+#ifndef QPWC_WARP_OCC
+#define QPWC_WARP_OCC 3   // waves per SIMD of the fused kernel (A/B: make ab ABFLAGS=-DQPWC_WARP_OCC=4)
+#endif
+template <bool WARP>
+__global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfma_lds_kernel(
+    const float* __restrict__ prv, const float* __restrict__ nxt, const float* __restrict__ flo,
+    float* __restrict__ out, int H, int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope,
+    float inv_c, int pad84) {
     __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytes];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -489,6 +504,33 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
         goff[8] = okp ? base_p : kOob;
         goff[9] = okp ? base_p + 4u * rowb : kOob;
     }
+    // ---- WARP: corner (y0, x0) byte offset + chunk and the two lerp factors of the eight nxt pieces ----
+    float wax[WARP ? 8 : 1], way[WARP ? 8 : 1];
+    const unsigned pixb = (unsigned)C * 4u, rowb2 = (unsigned)W * pixb;
+    if (WARP) {
+        // this lane's share: piece it = sc, i.e. nxt block (sc >> 1, 2 (sc & 1) + hi), pixel (spy, spx)
+        const int yy = Y0 - 4 + 4 * (sc >> 1) + spy, xx = X0 - 4 + 4 * (2 * (sc & 1) + hi) + spx;
+        const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float2 f = make_float2(0.f, 0.f);
+        if (inside) f = *reinterpret_cast<const float2*>(flo + ((int64_t)(b * H + yy) * W + xx) * 2);
+        const Taps t = taps_clamp(yy, xx, f.x, f.y, H, W);
+        uint4 rec;
+        rec.x = inside ? (unsigned)(t.y0 * W + t.x0) * pixb : kOob;   // outside: every corner reads zero
+        rec.y = __float_as_uint(t.ax);
+        rec.z = __float_as_uint(t.ay);
+        rec.w = 0u;
+        char* xch = smem + wave * 1024 + (lane >> 3) * 128;   // 8 records of the lane group
+        *reinterpret_cast<uint4*>(xch + sc * 16) = rec;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint4 r = *reinterpret_cast<const uint4*>(xch + it * 16);
+            goff[it] = r.x + (unsigned)sc * 16u;
+            wax[it] = __uint_as_float(r.y);
+            way[it] = __uint_as_float(r.z);
+        }
+        __builtin_amdgcn_wave_barrier();   // the records are in registers before this wave's staging writes
+    }
 
     // ---- operand map (matrix-core layout): lane = pixel n, k-slot g ------------
     const int n = lane & 15, g = lane >> 4;
@@ -504,14 +546,59 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_kernel(
     auto step = [&](int s, auto first) {
         constexpr bool FIRST = decltype(first)::value;
         const int soff = s * 128;
-        u32x4 st[10];
+        if (WARP) {
+            // PR pieces per round: 4 PR corner loads in flight, blended and written to LDS at once.  Holding all
+            // ten staged pieces in registers as the unfused form does is out of reach (32 corner chunks); the
+            // fused kernel runs 3 waves per SIMD (<= 168 registers) so that a round can be 4 pieces.
+            constexpr int PR = (FIRST && QPWC_WARP_OCC < 4) ? 4 : 2;   // later steps carry the 36 accumulators as well
+            u32x4 sp[2];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
+            for (int it = 8; it < 10; ++it) sp[it - 8] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[it], soff, 0);
+            u32x4 c[PR][4];
+            auto issue = [&](int it) {
 #pragma unroll
-        for (int it = 8; it < 10; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[it], soff, 0);
-        if (!FIRST) __syncthreads();  // previous step's operand reads are done
+                for (int q = 0; q < PR; ++q) {
+                    // the corner deltas ride in the scalar offset (clamp mode: all four corners of a pixel inside
+                    // the image are inside the image; a pixel outside has voffset >= 2^31 = out of range)
+                    const unsigned o = goff[it + q];
+                    c[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff, 0);
+                    c[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)pixb, 0);
+                    c[q][2] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)rowb2, 0);
+                    c[q][3] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)(rowb2 + pixb), 0);
+                }
+            };
+            issue(0);
+            if (!FIRST) __syncthreads();  // previous step's operand reads are done
 #pragma unroll
-        for (int it = 0; it < 10; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = st[it];
+            for (int it = 0; it < 8; it += PR) {
+                u32x4 v[PR];
+#pragma unroll
+                for (int q = 0; q < PR; ++q) {
+                    Taps t;
+                    t.ax = wax[it + q];
+                    t.ay = way[it + q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[q][e] = __float_as_uint(blend<QPWC_WARP_CLAMP>(
+                            t, __uint_as_float(c[q][0][e]), __uint_as_float(c[q][1][e]),
+                            __uint_as_float(c[q][2][e]), __uint_as_float(c[q][3][e])));
+                }
+                if (it + PR < 8) issue(it + PR);
+#pragma unroll
+                for (int q = 0; q < PR; ++q) *reinterpret_cast<u32x4*>(smem + lds_w + (it + q) * 4096) = v[q];
+            }
+#pragma unroll
+            for (int it = 8; it < 10; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = sp[it - 8];
+        } else {
+            u32x4 st[10];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
+#pragma unroll
+            for (int it = 8; it < 10; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[it], soff, 0);
+            if (!FIRST) __syncthreads();  // previous step's operand reads are done
+#pragma unroll
+            for (int it = 0; it < 10; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = st[it];
+        }
         if (FIRST) asm volatile("" : "+v"(tab.x), "+v"(tab.y), "+v"(tab.z), "+v"(tab.w));
         __syncthreads();
 #pragma unroll
@@ -685,7 +772,7 @@ static int lds_mode() {
 static constexpr int lds_mode() { return 1; }
 #endif
 
-static int launch_lds(const float* prv, const float* nxt, float* out, int B, int H, int W, int C,
+static int launch_lds(const float* prv, const float* nxt, const float* flo, float* out, int B, int H, int W, int C,
                       int64_t ops, float slope, int pad84, hipStream_t s) {
     const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
     const int64_t nblk = (int64_t)regs_x * regs_y * B;
@@ -695,14 +782,19 @@ static int launch_lds(const float* prv, const float* nxt, float* out, int B, int
         return QPWC_E_SHAPE;
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
+    if (flo) {
+        hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
+                           flo, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
+        return check_launch("cost_volume_mfma_lds_kernel<warp>");
+    }
 #ifdef QPWC_EXPERIMENTAL
     {
         const int rc = launch_experimental(prv, nxt, out, H, W, C, regs_x, regs_y, nblk, ops, slope, inv_c, s);
         if (rc <= 0) return rc;
     }
 #endif
-    hipLaunchKernelGGL(cost_volume_mfma_lds_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, out,
-                       H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
+    hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
+                       (const float*)nullptr, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_lds_kernel");
 }
 
@@ -747,11 +839,16 @@ static int dispatch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W
 // pad84: `out` pixels are 84 floats apart and channels 81..83 are to be zero.  The dense epilogue
 // writes them itself; *pads_written says whether every tile of this launch takes that path (if not, the
 // caller zeroes the pads with its own small launch).
-int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, int H, int W, int C,
-                            int dtype, int64_t ops, float slope, int pad84, bool* pads_written,
+// flo != nullptr: the fused WarpV2 + cost volume (fp32, workgroup-shared kernel only; returns 1 for shapes
+// that kernel does not take, and the caller uses the LDS-tiled vector kernel's fused form).
+int cost_volume_mfma_launch(const void* prv, const void* nxt, const void* flo, void* out, int B, int H, int W,
+                            int C, int dtype, int64_t ops, float slope, int pad84, bool* pads_written,
                             hipStream_t s) {
     if (pads_written) *pads_written = false;
     if (C % 16 != 0 || (reinterpret_cast<uintptr_t>(prv) | reinterpret_cast<uintptr_t>(nxt)) % 16)
+        return 1;
+    if (flo && (dtype != QPWC_F32 || C % 32 != 0 || reinterpret_cast<uintptr_t>(flo) % 8 || H < 2 || W < 2 ||
+                (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B < 256))
         return 1;
     // 32-bit byte offsets inside one image (buffer descriptors) and 32-bit element offsets
     // inside one output image: larger problems take the 64-bit vector kernel instead
@@ -767,7 +864,8 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, void* out, int B, 
             // every tile dense: full 4x4 tiles, 16-byte aligned rows
             if (pads_written)
                 *pads_written = pad84 && W % 4 == 0 && H % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
-            return launch_lds((const float*)prv, (const float*)nxt, (float*)out, B, H, W, C, ops, slope, pad84, s);
+            return launch_lds((const float*)prv, (const float*)nxt, (const float*)flo, (float*)out, B, H, W, C, ops,
+                              slope, pad84, s);
         }
         if (C % 32 == 0)
             return dispatch_mfma<float, 8>((const float*)prv, (const float*)nxt, (float*)out, B, H, W,

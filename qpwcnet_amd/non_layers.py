@@ -507,22 +507,36 @@ class Flow(_Weighted):
         return self.flow(feat)
 
 
-def _cost84(prv, nxt, search_range):
+def _cost84(prv, nxt, search_range, flo=None):
     """The cost volume as (B,H,W,84): 81 channels + 3 zeros, pixels 16-byte aligned (the layout the fused
-    first OptFlow layer reads with 16-byte loads)."""
+    first OptFlow layer reads with 16-byte loads).  With `flo`: of prv against WarpV2(nxt, flo), one launch."""
     cost = torch.empty(prv.shape[:3] + (84,), dtype=prv.dtype, device=prv.device)
-    ops.cost_volume_into(prv.contiguous(), nxt.contiguous(), cost, 0, search_range, 0.1)
+    ops.cost_volume_into(prv.contiguous(), nxt.contiguous(), cost, 0, search_range, 0.1, flo=flo)
     return cost
+
+
+def fused_front_end_applies(prv, flo, search_range=4):
+    """True where qpwc_warp_cost_volume_fwd runs on the matrix cores (WarpV2 gathered in the staging step of
+    the workgroup-shared cost-volume kernel): channels-last fp32, C % 32 == 0, >= 256 regions of 8 x 8
+    pixels -- the same rule as cost_volume_mfma_launch.  tools/kbench.py, B=8: L2 14.4 vs 10.5 + 8.1 us for
+    warp + cost volume, L3 25.9 vs 17.9 + 9.6, L4 48.3 vs 36.1 + 16.9.  Elsewhere (few regions: the per-wave
+    split-K kernel's territory) two launches are faster than the LDS-tiled vector kernel's fused form."""
+    if not (prv.is_cuda and prv.dtype == torch.float32 and prv.dim() == 4 and search_range == 4 and
+            flo.dtype == torch.float32):
+        return False
+    B, H, W, C = prv.shape
+    return C % 32 == 0 and H >= 2 and W >= 2 and B * ((H + 7) // 8) * ((W + 7) // 8) >= 256
 
 
 class UpFlow(_Weighted):
     """Refinement block, qpwcnet/core/non_layers.py:341-387:
     nxt_w = WarpV2(nxt, flo); cost = cv(prv, nxt_w); OptFlow(concat[cost, prv, flo]).
 
-    fused=True (channels_last only) produces the same ``feat`` with one
-    warp+cost-volume launch writing straight into the concat buffer."""
+    fused (channels_last): WarpV2 and the cost volume as ONE launch (nxt_w never
+    exists in memory) feeding OptFlow.from_sources like the unfused form.  None (default) / True: wherever
+    the matrix-core fused kernel applies (fused_front_end_applies); False: never."""
 
-    def __init__(self, params, prefix, use_tfa=True, fused=False, hip_optflow=True, *args, **kwargs):
+    def __init__(self, params, prefix, use_tfa=True, fused=None, hip_optflow=True, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
         self._config = {"use_tfa": use_tfa}
         self.hip_optflow = bool(hip_optflow)
@@ -530,13 +544,17 @@ class UpFlow(_Weighted):
         self.warp = WarpV2(data_format=self.data_format)
         cls = CostVolumeV2 if use_tfa else CostVolume
         self.cost_volume = cls(data_format=self.data_format)
-        self.fused = bool(fused) and self.data_format == CHANNELS_LAST
+        self.fused = (fused is None or bool(fused)) and self.data_format == CHANNELS_LAST and self.hip_optflow
 
     def __call__(self, inputs):
         prv, nxt, flo = inputs
-        if self.fused:
-            feat = self._fused_feat(prv, nxt, flo)
-            return self.flow(feat)
+        r = self.cost_volume.search_range
+        if self.fused and fused_front_end_applies(prv, flo, r):
+            if self.flow.wants_cost84(prv):
+                cost = _cost84(prv, nxt, r, flo=flo.contiguous())
+            else:
+                cost = ops.warp_cost_volume(prv.contiguous(), nxt.contiguous(), flo.contiguous(), r, 0.1)
+            return self.flow.from_sources((cost, prv, flo))
         nxt_w = self.warp((nxt, flo))
         if self.hip_optflow and self.flow.wants_cost84(prv):
             cost = _cost84(prv, nxt_w, self.cost_volume.search_range)
@@ -546,17 +564,6 @@ class UpFlow(_Weighted):
             return self.flow.from_sources((cost, prv, flo))
         feat = torch.cat([cost, prv, flo], dim=self.axis)
         return self.flow(feat)
-
-    def _fused_feat(self, prv, nxt, flo):
-        B, H, W, C = prv.shape
-        d2 = (2 * self.cost_volume.search_range + 1) ** 2
-        feat = torch.empty((B, H, W, d2 + C + 2), dtype=prv.dtype, device=prv.device)
-        flo32 = flo.to(torch.float32).contiguous()
-        ops.cost_volume_into(prv.contiguous(), nxt.contiguous(), feat, 0,
-                             self.cost_volume.search_range, 0.1, flo=flo32)
-        feat[..., d2:d2 + C] = prv
-        feat[..., d2 + C:] = flo
-        return feat
 
 
 class FrameInterpolate(_Weighted):

@@ -92,7 +92,7 @@ class QpwcNet:
     multi-scale flows when ``train`` (pwcnet.py:237-239) else the final flow only."""
 
     def __init__(self, weights, train=True, input_shape=(256, 512), data_format=None,
-                 use_tfa=True, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True,
+                 use_tfa=True, device="cuda", dtype=torch.float32, fused=None, hip_optflow=True,
                  batch_frames=True, overlap_streams=True, internal_channels_last=True):
         self.data_format = image_data_format() if data_format is None else data_format
         self.axis = get_axis(self.data_format)
@@ -368,7 +368,7 @@ def build_interpolator(input_shape=(256, 512), data_format=None, use_tfa=True, w
 
 
 def build_flower(train=True, input_shape=(256, 512), data_format=None, use_tfa=True,
-                 weights=None, device="cuda", dtype=torch.float32, fused=False, hip_optflow=True):
+                 weights=None, device="cuda", dtype=torch.float32, fused=None, hip_optflow=True):
     """pwcnet.py:210-244.  ``weights``: flat dict from ``synth.make_weights`` (default:
     seed 42), since no checkpoint ships with the reference."""
     if weights is None:
