@@ -411,7 +411,7 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
     # (CPU rehearsal of the N > 1 path, --dist-backend gloo: the same submit/collect pattern on host tensors)
     gloo = args.dist_backend == "gloo"
     gather = qdist.EpeGather(6, "cpu" if gloo else dev, n_local=B)
-    in_place = gather.collective and not gloo   # the graphs' EPE reductions write the payload themselves
+    in_place = not gloo and not args.no_graph   # the graphs' EPE reductions write the payload themselves
 
     graphs = None
     if not args.no_graph:
@@ -464,8 +464,8 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
             "global_batch": world * B, "batch_per_gpu": B,
             "parallelism": "dp{} (pairs sharded, RCCL all-gather of the 6 per-level EPE)".format(world),
             "hipgraph": graphs is not None,
-            "epe_payload": ("written by the captured EPE reduction (two graphs, one pool)" if graphs is not None
-                            and in_place else ("copied per step" if gather.collective else "single process")),
+            "epe_payload": ("written by the captured EPE reduction (two graphs over one memory pool, replayed "
+                            "alternately; no per-step copy)" if graphs is not None and in_place else "copied per step"),
             # levels L1..L4 whose UpFlow runs WarpV2 + cost volume as one launch
             "fused_upflow": [bool(u.fused) and tdtype == torch.float32 and
                              B * (((hw[0] >> (4 - i)) + 7) // 8) * (((hw[1] >> (4 - i)) + 7) // 8) >= 256

@@ -76,21 +76,14 @@ int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, v
                           hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
 
-// float4 streaming copy: the box's achievable HBM ceiling (read + write) for bench.py's roofline block.
+// 16-byte-per-lane streaming copy: the box's achievable HBM ceiling (read + write) for bench.py's roofline
+// block.  tools/micro/copybench.hip on MI355X: one float4 per thread over a one-shot grid with non-temporal
+// loads and stores 6.5 TB/s (plain 6.1; 4 float4 per thread over a grid-strided loop 5.5-6.2; hipMemcpyAsync 5.3).
 typedef unsigned int copy_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void device_copy_kernel(const copy_u32x4* __restrict__ src,
                                                          copy_u32x4* __restrict__ dst, int64_t n16) {
-    // every workgroup walks contiguous 16 KB chunks (256 lanes x 16 B x 4), grid-strided
-    const int64_t stride = (int64_t)gridDim.x * 1024;
-    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += stride) {
-        copy_u32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i + 256 * u < n16) v[u] = src[i + 256 * u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i + 256 * u < n16) dst[i + 256 * u] = v[u];
-    }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 static int fail(int code, const char* fmt, ...) {
@@ -175,8 +168,9 @@ int qpwc_device_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     if (((uintptr_t)src | (uintptr_t)dst) % 16) return fail(QPWC_E_ALIGN, "pointers must be 16-byte aligned");
     if (overlaps(dst, (size_t)bytes, src, (size_t)bytes)) return fail(QPWC_E_ALIAS, "dst overlaps src");
     const int64_t n16 = bytes / 16;
-    const int64_t want = (n16 + 1023) / 1024;
-    const unsigned grid = (unsigned)(want < 256 * 16 ? want : 256 * 16);   // <= 16 workgroups per CU
+    const int64_t want = (n16 + 255) / 256;
+    if (want > INT32_MAX) return fail(QPWC_E_SHAPE, "copy of %lld bytes needs too many workgroups", (long long)bytes);
+    const unsigned grid = (unsigned)want;
     hipLaunchKernelGGL(device_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const copy_u32x4*)src, (copy_u32x4*)dst, n16);
     return check_launch("device_copy_kernel");

@@ -112,12 +112,14 @@ class EpeGather:
                 raise ValueError("EpeGather.submit: pass a vector or a slot, not both")
             if slot != k:
                 raise RuntimeError("EpeGather: slot {} submitted, slot {} is next".format(slot, k))
-        else:
-            self.payload[k][:self.L].copy_(local_epe)
         self.slot ^= 1
         if not self.collective:
-            self.pending.append((None, self.payload[k][:self.L].clone()))
+            # single process: nothing to exchange and nothing to copy.  A slot result is the payload window
+            # itself (valid until the slot comes round again, two steps later); a vector is kept as a clone.
+            self.pending.append((None, self.payload[k][:self.L] if slot is not None else local_epe.clone()))
             return
+        if slot is None:
+            self.payload[k][:self.L].copy_(local_epe)
         work = dist.all_gather_into_tensor(self.flat[k], self.payload[k], async_op=True)
         self.pending.append((work, self.flat[k]))
 

@@ -216,6 +216,12 @@ class QpwcNet:
         # level, whose quarter launches are only 128 workgroups: another -0.7 %)
         small = encs[-1].shape[0] <= 32
         chunks = 2 if small else 1
+        # The coarsest flow block first, THEN the decoder launches: in the captured graph the first node
+        # created after the fork stays on the encoder's hardware queue and the other branch starts on a second
+        # queue some 50-100 us later (kernel trace of the replay: with the decoder captured first, the flow
+        # chain -- the critical path -- was the branch that waited).  The decoder has that much slack.
+        flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
+        flos = [flo]
         with torch.cuda.stream(side):
             f, i = encs[-1], -2
             for li, l in enumerate(self.dec):
@@ -230,8 +236,6 @@ class QpwcNet:
                 ev = torch.cuda.Event()
                 ev.record(side)
                 ready.append(ev)
-        flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
-        flos = [flo]
         for i, upflow in enumerate(self.upflows):
             flo_u = self._up(flo)
             main.wait_event(ready[i])
