@@ -320,6 +320,9 @@ constexpr int kScTH = 8, kScTW = 16;    // pixel tile
 constexpr int kScHH = kScTH + 2, kScHW = kScTW + 2;
 constexpr int kScNH = kScHH * kScHW;    // 180 halo pixels
 constexpr int kScInPS = 40;             // floats per halo pixel in in_s
+#ifdef QPWC_SC_STAMP
+__device__ long long g_sc_stamps[4 * 64];
+#endif
 
 __device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -340,6 +343,16 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int X0 = tx * kScTW, Y0 = ty * kScTH;
     const int n = lane & 15, g = lane >> 4;
+#ifdef QPWC_SC_STAMP
+    // diagnostic build only (make ab ABSRC=optflow ABFLAGS=-DQPWC_SC_STAMP): shader-clock stamps of one wave
+    // of a few workgroups, read back through qpwc_debug_sc_stamps(); no stamp touches an output
+    const bool stamp_on = lane == 0 && wave == 0 && (blockIdx.x % 509) == 7 && blockIdx.x / 509 < 4;
+    long long* stamp_p = g_sc_stamps + (blockIdx.x / 509) * 64;
+    int stamp_i = 0;
+#define SC_STAMP() do { if (stamp_on && stamp_i < 62) stamp_p[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SC_STAMP() do { } while (0)
+#endif
 
     f32x4v acc[2][NFT];
 #pragma unroll
@@ -386,29 +399,24 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 p += (int64_t)b * H * W * ps + cc;
             }
             {
-                // branch-free: halo pixels outside the image, channels past C and the lanes of a short last
-                // source (fixed up below) read a 16-byte block of zeros; pixel offset x pixel stride is a
-                // 24-bit multiply (the launcher checks H*W < 2^24)
-                const bool full = left >= 4;
+                // branch-free: halo pixels outside the image and channels past C read a 16-byte block of zeros;
+                // pixel offset x pixel stride is a 24-bit multiply (the launcher checks H*W < 2^24).
+                // A short last source (Flow/UpFlow's 2-channel flow: `left` = 1..3 channels from c on) is read
+                // with the SAME 16-byte load, moved back by 4 - left floats so that it ENDS at the source's last
+                // channel (the front of the quad then holds the previous pixel's trailing channels); commit_in()
+                // re-aligns and zero-fills.  The very first pixel of the tensor has nothing in front of it and
+                // reads forward instead (the launcher checks that the tensor holds >= 4 floats past it).
+                // Element loads here made the wave wait for its prefetch in the middle of the matrix phase.
+                const bool full = left >= 4, tail = left > 0 && left < 4;
+                const int back = tail ? 4 - left : 0;
 #pragma unroll
                 for (int it = 0; it < NST; ++it) {
-                    const bool ok = goff[it] >= 0 && full;
+                    const bool ok = goff[it] >= 0 && (full || tail);
                     const float* q = ok ? p : kScZeros;
-                    const unsigned off = ok ? __umul24((unsigned)goff[it], (unsigned)ps) : 0u;
-                    st4[it] = *reinterpret_cast<const float4*>(q + off);
-                }
-            }
-            // a short last source (Flow/UpFlow's 2-channel flow): element loads, once per launch, behind ONE
-            // wave-uniform branch (per-lane branches here cost 26 exec-mask sequences in every step)
-            const bool tail = left > 0 && left < 4;
-            if (__builtin_amdgcn_ballot_w64(tail) != 0) {
-                const int i1 = left > 1 ? 1 : 0, i2 = left > 2 ? 2 : 0;   // never past the source's channels
-#pragma unroll
-                for (int it = 0; it < NST; ++it) {
-                    const bool ok = tail && goff[it] >= 0;
-                    const float* q = ok ? p + __umul24((unsigned)(ok ? goff[it] : 0), (unsigned)ps) : kScZeros;
-                    const float e0 = q[0], e1 = q[ok ? i1 : 0], e2 = q[ok ? i2 : 0];
-                    if (tail) st4[it] = make_float4(ok ? e0 : 0.f, (ok && left > 1) ? e1 : 0.f, (ok && left > 2) ? e2 : 0.f, 0.f);
+                    unsigned off = ok ? __umul24((unsigned)goff[it], (unsigned)ps) : 0u;
+                    const bool first = b == 0 && goff[it] == 0;
+                    if (ok && tail && !first) off -= (unsigned)back;
+                    st4[it] = *reinterpret_cast<const float4*>(q + (int)off);
                 }
             }
         }
@@ -431,6 +439,28 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     };
     auto commit_in = [&](int c0) {  // registers -> in_s, dw_s
         if (VEC) {
+            // the quad of a short last source was loaded ending at its last channel (fetch_in): move its
+            // `left` channels to the front, zero the rest -- one wave-uniform branch, taken in one step per tile
+            const int c = c0 + sch;
+            const int nfull = src.ch[0] + src.ch[1] + src.ch[2];
+            int left = 4;
+            if (c < nfull) {
+                const int e0 = src.ch[0], e1 = e0 + src.ch[1];
+                left = (c < e0 ? e0 : (c < e1 ? e1 : nfull)) - c;
+            }
+            const bool tail = left < 4;
+            if (__builtin_amdgcn_ballot_w64(tail) != 0) {
+#pragma unroll
+                for (int it = 0; it < NST; ++it) {
+                    const float4 v = st4[it];
+                    const bool fwd = (b == 0 && goff[it] == 0) || goff[it] < 0;   // forward (or zero block): no shift
+                    const int sh = fwd ? 0 : 4 - left;
+                    const float a0 = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
+                    const float a1 = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);
+                    const float a2 = sh == 0 ? v.z : v.w;
+                    if (tail) st4[it] = make_float4(a0, left > 1 ? a1 : 0.f, left > 2 ? a2 : 0.f, 0.f);
+                }
+            }
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
                 const int hp = sps + SPT * it;
@@ -546,17 +576,22 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     //   B: staged                                 -> prefetch, pointwise(k) || depthwise(k+1)
     const int nsteps = cpad / kScKC;
     constexpr int kYs = kScTH * kScTW * kScKC;
+    SC_STAMP();
     fetch_in(0);
     fetch_w(0);
     commit_in(0);
     __syncthreads();
+    SC_STAMP();
     if (nsteps > 1) fetch_in(kScKC);
     depthwise(y_s);
+    SC_STAMP();
     for (int k = 0; k + 1 < nsteps; ++k) {
         __syncthreads();
+        SC_STAMP();
         commit_w();
         commit_in((k + 1) * kScKC);
         __syncthreads();
+        SC_STAMP();
         fetch_w((k + 1) * kScKC);
         if (k + 2 < nsteps) fetch_in((k + 2) * kScKC);
         pointwise(y_s + (k & 1) * kYs);
@@ -570,31 +605,64 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
             __builtin_amdgcn_sched_group_barrier(0x100, (40 + kNM - 1) / kNM, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, (120 + kNM - 1) / kNM, 0);
         }
+        SC_STAMP();
     }
     __syncthreads();
+    SC_STAMP();
     commit_w();
     __syncthreads();
-    asm volatile("; last step: matrix work only");
-    pointwise(y_s + ((nsteps - 1) & 1) * kYs);
-    // ---- bias + store: lane = pixel n of a 16-pixel row segment, outputs 16 ft + 4 g .. + 3 ----
+    SC_STAMP();
+    asm volatile("; last step: matrix work, block of 16 outputs by block, each block's bias + Mish + stores behind it");
+    // The accumulators of output block ft are final after its 16 matrix instructions: its epilogue (bias,
+    // Mish, two 16-byte stores) issues in the matrix pipe's shadow of block ft + 1 instead of after all of
+    // them (phase stamps, F = 128: 4.7 k cycles of matrix work followed by 9-12 k cycles of epilogue).
+    {
+        const float* ys = y_s + ((nsteps - 1) & 1) * kYs;
+        f32x4v yv[2][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int pix = 32 * wave + 16 * m + n;
-        const int gy = Y0 + pix / kScTW, gx = X0 + pix % kScTW;
-        if (gy < H && gx < W) {
-            float* o = out + ((int64_t)(b * H + gy) * W + gx) * F;
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int ft = 0; ft < NFT; ++ft) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+            for (int m = 0; m < 2; ++m)
+                yv[u][m] = *reinterpret_cast<const f32x4v*>(ys + (32 * wave + 16 * m + n) * kScKC + (((4 * u + g) ^ sw) << 2));
+        float* orow[2];
+        bool ook[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int pix = 32 * wave + 16 * m + n;
+            const int gy = Y0 + pix / kScTW, gx = X0 + pix % kScTW;
+            ook[m] = gy < H && gx < W;
+            orow[m] = out + ((int64_t)(b * H + gy) * W + gx) * F + 4 * g;
+        }
+        auto epilogue = [&](int ft) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
                 float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
                                        acc[m][ft][3] + bv.w);
-                // the activation applied once per output element instead of once per (halo) load
-                // of the next layer
+                // the activation applied once per output element instead of once per (halo) load of the next layer
                 if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
-                *reinterpret_cast<float4*>(o + 16 * ft + 4 * g) = z;
+                if (ook[m]) *reinterpret_cast<float4*>(orow[m] + 16 * ft) = z;
             }
+        };
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            f32x4v wv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                wv[u] = *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScKC + (((4 * u + g) ^ sw) << 2));
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t], yv[u][m][t], acc[m][ft], 0, 0, 0);
+            if (ft > 0) epilogue(ft - 1);
         }
+        SC_STAMP();
+        epilogue(NFT - 1);
     }
+    SC_STAMP();
 }
 
 // ---------------------------------------------------------------------------
@@ -914,6 +982,8 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
         const bool aligned = chans[i] % 4 == 0 && strides[i] % 4 == 0 && reinterpret_cast<uintptr_t>(srcs[i]) % 16 == 0;
         if (!aligned && i + 1 < n_src) vec = false;                  // only the last source may be odd
         if (!aligned && i + 1 == n_src && chans[i] >= 4) vec = false; // ... and only if it is a short tail
+        // the tail quad of the very first pixel is read forward: the tensor must hold 4 floats from there
+        if (!aligned && i + 1 == n_src && (int64_t)B * H * W * strides[i] < 4) vec = false;
         // the 16-byte path multiplies pixel offset and pixel stride as 24-bit integers into 32 bits
         if ((int64_t)H * W >= (1 << 24) || strides[i] >= (1 << 24) || (int64_t)H * W * strides[i] >= ((int64_t)1 << 32))
             vec = false;
@@ -1235,3 +1305,10 @@ int flow_head_launch(const void* z, const void* params, void* out, int B, int H,
 }
 
 }  // namespace qpwc
+
+#ifdef QPWC_SC_STAMP
+extern "C" int qpwc_debug_sc_stamps(long long* out, int n) {
+    if (n > 4 * 64) n = 4 * 64;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qpwc::g_sc_stamps), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
