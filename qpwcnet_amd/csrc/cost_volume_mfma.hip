@@ -458,6 +458,12 @@ constexpr int kRegLdsBytes = kRegStageBytes > 4 * kFrameFloats * 4 ? kRegStageBy
 // ZeroPadding2D of the WARPED image: zero, not sampled.  A lane computes the taps of ONE of its eight
 // pieces (the eight lanes of a pixel would all compute the same ones) and the group shares them through
 // the 1 KB of the staging area that only its own wave writes later.
+#ifdef QPWC_CV_STAMP
+__device__ long long g_cv_stamps[8 * 16];
+#define CV_STAMP() do { if (cv_stamp_on && cv_si < 16) cv_sp[cv_si++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CV_STAMP() do { } while (0)
+#endif
 #ifndef QPWC_WARP_OCC
 #define QPWC_WARP_OCC 3   // waves per SIMD of the fused kernel (A/B: make ab ABFLAGS=-DQPWC_WARP_OCC=4)
 #endif
@@ -473,6 +479,13 @@ __global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfm
     const int region = xcd_swizzle(blockIdx.x, gridDim.x);
     const int rx = region % regs_x, ry = (region / regs_x) % regs_y, b = region / (regs_x * regs_y);
     const int X0 = rx * 8, Y0 = ry * 8;
+#ifdef QPWC_CV_STAMP
+    // diagnostic build only (make ab ABFLAGS=-DQPWC_CV_STAMP): shader-clock stamps of wave 0 of 8 workgroups
+    const bool cv_stamp_on = lane == 0 && wave == 0 && (blockIdx.x % 509) == 3 && blockIdx.x / 509 < 8;
+    long long* cv_sp = g_cv_stamps + (blockIdx.x / 509) * 16;
+    int cv_si = 0;
+#endif
+    CV_STAMP();
 
     const int img_bytes = H * W * C * 4;  // < 2^31, checked on the host
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
@@ -595,12 +608,15 @@ __global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfm
             for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
 #pragma unroll
             for (int it = 8; it < 10; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[it], soff, 0);
+            if (FIRST) CV_STAMP();   // loads issued
             if (!FIRST) __syncthreads();  // previous step's operand reads are done
 #pragma unroll
             for (int it = 0; it < 10; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = st[it];
+            if (FIRST) CV_STAMP();   // loads landed, written to LDS
         }
         if (FIRST) asm volatile("" : "+v"(tab.x), "+v"(tab.y), "+v"(tab.z), "+v"(tab.w));
         __syncthreads();
+        if (FIRST) CV_STAMP();       // barrier: image complete
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int coff = (((4 * u + g) ^ sw) << 4) + lds_r;
@@ -624,7 +640,9 @@ __global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfm
     };
     step(0, std::true_type{});
     for (int s = 1; s < nsteps; ++s) step(s, std::false_type{});
+    CV_STAMP();       // matrix work issued
     __syncthreads();  // staging area becomes the four output frames
+    CV_STAMP();
 
     float* fr = reinterpret_cast<float*>(smem) + wave * kFrameFloats;
     {
@@ -635,11 +653,17 @@ __global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfm
             for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(dst + 48 * i + 4 * j) = acc[i][j];
     }
     __builtin_amdgcn_wave_barrier();
+    CV_STAMP();       // frame written (includes the wait for the last matrix results)
 
     const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
     if (x0 >= W || y0 >= H) return;
     float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
     store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab, pad84 != 0);
+    CV_STAMP();       // read back, activated, stores issued
+#ifdef QPWC_CV_STAMP
+    asm volatile("s_waitcnt vmcnt(0)");
+    CV_STAMP();       // stores acknowledged
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -896,6 +920,13 @@ extern "C" const char* qpwc_build_info(void) {
     return "libqpwc_hip gfx950 product (no environment switches)";
 #endif
 }
+
+#ifdef QPWC_CV_STAMP
+extern "C" int qpwc_debug_cv_stamps(long long* out, int n) {
+    if (n > 8 * 16) n = 8 * 16;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qpwc::g_cv_stamps), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 #if defined(QPWC_EXPERIMENTAL) && defined(QPWC_STAMP)
 #include "experimental/debug_exports.inc"
