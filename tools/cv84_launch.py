@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The bench step's own L4 cost-volume launch (8x128x256x32 fp32, 84-float output pixels) and the L4
-WarpV2, a dozen times each: the program tools/pmc.sh profiles for profiles/traffic.json."""
+"""The bench step's own L4 hot-path launches (8x128x256x32 fp32): the cost volume with 84-float output pixels,
+the WarpV2, and the fused WarpV2 + cost volume, a dozen times each -- the program tools/make_traffic.sh
+profiles for profiles/traffic.json."""
 import os
 import sys
 
@@ -17,4 +18,5 @@ buf = torch.empty(8, 128, 256, 84, device="cuda")
 for _ in range(13):
     ops.cost_volume_into(prv, nxt, buf, 0)
     ops.warp(nxt, flo, "clamp")
+    ops.cost_volume_into(prv, nxt, buf, 0, flo=flo)
 torch.cuda.synchronize()

@@ -1,30 +1,45 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from a tools/pmc.sh run: HBM bytes per launch of the dominant
-hot-path kernel, from the FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs).
+"""profiles/traffic.json from a tools/pmc.sh run: HBM bytes per launch of the hot-path kernels, from the
+FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs).
 
-Corrections per MI355X_MICROARCH.md (HBM section): both counters are in KiB;
-on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced
-streaming read -> doubled; WRITE_SIZE is exact for streaming stores."""
+Corrections per MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for
+streaming stores.  The file is stamped with the sha256 of the kernel sources (qpwcnet_amd._hip.source_sha256):
+bench.py drops `roofline.traffic` when the sources have changed since.
+
+usage: traffic_from_pmc.py <pmc dir> <out.json> <tag> <key>=<kernel substring> [...]"""
 import csv
 import glob
 import json
 import os
 import sys
 
-root, kernel_substr, key, out = sys.argv[1:5]
-vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qpwcnet_amd import _hip  # noqa: E402
+
+root, out, tag = sys.argv[1:4]
+pairs = [a.split("=", 1) for a in sys.argv[4:]]
+rows = []
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] in vals:
+    rows += list(csv.DictReader(open(f)))
+d = {"kernel_source_sha256": _hip.source_sha256(), "tag": tag,
+     "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/cv84_launch.py "
+             "(tools/make_traffic.sh); FETCH_SIZE KiB x2 (gfx950 16-B/lane correction), WRITE_SIZE KiB; the "
+             "cost-volume launches write 84-float pixels (81 channels + 3 zeroed pads), the algorithmic bytes "
+             "count 81"}
+for key, sub in pairs:
+    vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    for r in rows:
+        if sub in r["Kernel_Name"] and r["Counter_Name"] in vals:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024 * 2
-write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
-d = json.load(open(out)) if os.path.exists(out) else {}
-d[key] = fetch + write
-d[key + "_detail"] = {
-    "kernel": kernel_substr, "launches": len(vals["FETCH_SIZE"]),
-    "FETCH_SIZE_KiB_raw": sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]),
-    "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "source": root,
-}
+    if not vals["FETCH_SIZE"] or not vals["WRITE_SIZE"]:
+        print("no counters for", key, sub)
+        continue
+    fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024 * 2
+    write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
+    d[key] = fetch + write
+    d[key + "_detail"] = {"kernel": sub, "launches": len(vals["FETCH_SIZE"]),
+                          "FETCH_SIZE_KiB_raw": sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]),
+                          "fetch_bytes_corrected_x2": fetch, "write_bytes": write}
+    print(key, fetch + write)
 json.dump(d, open(out, "w"), indent=1)
-print(key, fetch + write)
