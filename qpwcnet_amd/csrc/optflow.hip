@@ -329,7 +329,11 @@ __device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f
 template <int F, bool ACT, bool VEC, bool ACT_OUT>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     DwSrc src, const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y) {
+    float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y, int slices) {
+    // F = output channels of THIS workgroup.  slices > 1 (coarse levels: few tiles, many 32-channel steps): the
+    // layer's slices * F outputs are split over `slices` workgroups per tile -- each repeats the (cheap)
+    // depthwise convolution and takes 1 / slices of the matrix work, and the launch has slices x more
+    // workgroups for a chip the tiles alone would leave mostly idle.
     constexpr int NFT = F / 16;
     constexpr int NST = VEC ? 6 : 23;   // staging loads per thread and step
     __shared__ __attribute__((aligned(16))) float in_s[kScNH * kScInPS];
@@ -339,10 +343,15 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile = wg / slices, fslice = wg - tile * slices;   // the slices of a tile are neighbours (shared input)
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int X0 = tx * kScTW, Y0 = ty * kScTH;
     const int n = lane & 15, g = lane >> 4;
+    const int FT = F * slices;                    // output pixel stride
+    pw += (int64_t)fslice * F * cpad;
+    bias += fslice * F;
+    out += fslice * F;
 #ifdef QPWC_SC_STAMP
     // diagnostic build only (make ab ABSRC=optflow ABFLAGS=-DQPWC_SC_STAMP): shader-clock stamps of one wave
     // of a few workgroups, read back through qpwc_debug_sc_stamps(); no stamp touches an output
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
             const int pix = 32 * wave + 16 * m + n;
             const int gy = Y0 + pix / kScTW, gx = X0 + pix % kScTW;
             ook[m] = gy < H && gx < W;
-            orow[m] = out + ((int64_t)(b * H + gy) * W + gx) * F + 4 * g;
+            orow[m] = out + ((int64_t)(b * H + gy) * W + gx) * FT + 4 * g;
         }
         auto epilogue = [&](int ft) {
             const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
@@ -940,10 +949,10 @@ int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64
 template <int F>
 static void sepconv_dispatch(const DwSrc& d, int act, bool vec, const float* dw, const float* pw,
                              const float* bias, float* out, int H, int W, int C, int cpad, int tiles_x,
-                             int tiles_y, dim3 grid, hipStream_t s) {
+                             int tiles_y, dim3 grid, int slices, hipStream_t s) {
 #define QPWC_SC_LAUNCH(ACT, VEC, AO)                                                                      \
     hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, ACT, VEC, AO>), grid, dim3(256), 0, s, d, dw, pw, bias, \
-                       out, H, W, C, cpad, tiles_x, tiles_y)
+                       out, H, W, C, cpad, tiles_x, tiles_y, slices)
     const bool in_act = (act & 1) != 0, out_act = (act & 2) != 0;   // QPWC_MISH_ON_LOAD / _ON_STORE
     if (out_act) {
         if (in_act) { if (vec) QPWC_SC_LAUNCH(true, true, true); else QPWC_SC_LAUNCH(true, false, true); }
@@ -973,7 +982,11 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
         set_error("sepconv3x3: too many tiles");
         return QPWC_E_SHAPE;
     }
-    const dim3 grid((unsigned)nblk);
+    // few tiles (coarse pyramid levels): split the outputs over 2 / 4 / 8 workgroups per tile (slices of >= 16
+    // outputs) until the launch has ~one workgroup per CU
+    int slices = 1;
+    while (nblk * slices < 192 && F / (slices * 2) >= 16) slices *= 2;
+    const dim3 grid((unsigned)(nblk * slices));
     // 16-byte loads: every source but the last holds a multiple of 4 channels in 16-byte aligned
     // pixels; the last one either does too or is read element-wise (it must not straddle a quad
     // boundary with its predecessor, which the multiple-of-4 rule guarantees)
@@ -989,12 +1002,15 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
             vec = false;
     }
     const float *fdw = (const float*)dw, *fpw = (const float*)pw, *fb = (const float*)bias;
-    switch (F) {
-        case 128: sepconv_dispatch<128>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 64: sepconv_dispatch<64>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 32: sepconv_dispatch<32>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        case 16: sepconv_dispatch<16>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
-        default: set_error("sepconv3x3: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
+    if (F != 16 && F != 32 && F != 64 && F != 128) {
+        set_error("sepconv3x3: unsupported filter count %d (16/32/64/128)", F);
+        return QPWC_E_SHAPE;
+    }
+    switch (F / slices) {   // outputs per workgroup
+        case 128: sepconv_dispatch<128>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, slices, s); break;
+        case 64: sepconv_dispatch<64>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, slices, s); break;
+        case 32: sepconv_dispatch<32>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, slices, s); break;
+        default: sepconv_dispatch<16>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, slices, s); break;
     }
     return check_launch("sepconv3x3_fused_kernel");
 }

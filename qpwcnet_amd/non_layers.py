@@ -345,14 +345,17 @@ class OptFlow(_Weighted):
     BN_EPS = 1e-3
     # Fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd: depthwise result stays in LDS, pointwise
     # on the fp32 matrix cores) instead of dwconv + library GEMM: False / True = never / always,
-    # None = per layer (_fuse_layer).  tools/sepbench.py, B=8: L4 299 vs 388 us for the four layers,
-    # L3 97 vs 138; wide layers of a small level (few 8x16 tiles, many 32-channel steps) are faster
-    # split (first layer at L2 37 vs 23 us, at L0 82 vs 12 us; 128-channel layer at L0/L1 15 vs 10 us).
+    # None = per layer (_fuse_layer).  tools/sepbench.py, B=8 (us, fused vs depthwise kernel + library GEMM):
+    # L4 253 vs 360 for the four layers, L3 84 vs 130.  On the small levels the fused kernel splits a layer's
+    # outputs over 2-8 workgroups per tile (round 2): 128 -> 64 at L0 / L1 / L2 9.3 / 9.5 / 12.4 vs 9.8 / 10.8 /
+    # 17.9, first layer at L2 (211 channels, 128 tiles) 23.2 vs 22.9 as one launch instead of two; the wide
+    # first layers of L0 / L1 (593 / 339 channels on 8 / 32 tiles: 19 / 11 dependent 32-channel steps) stay
+    # split: 32.5 vs 12.6 and 22.2 vs 17.1.
     fused_sepconv = None
 
     @staticmethod
     def _fuse_layer(c_in, n_tiles):
-        return c_in <= 64 or (c_in <= 128 and n_tiles >= 128) or n_tiles >= 256
+        return c_in <= 128 or (c_in <= 256 and n_tiles >= 128) or n_tiles >= 256
 
     def __init__(self, params, prefix, filters=(128, 64, 32, 16), scale=None, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
