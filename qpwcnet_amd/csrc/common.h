@@ -10,6 +10,14 @@ namespace qpwc {
 
 constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, each with a private L2
 
+// The flow chain (cost volume, warp, OptFlow, upsample: the critical path of a forward) shares the chip with
+// the decoder's chip-filling launches on a second hardware queue; its waves ask for issue priority over
+// co-resident decoder waves.  (Stream priorities do not survive hipGraph capture on this ROCm.)
+#ifndef QPWC_FLOW_PRIO
+#define QPWC_FLOW_PRIO 2
+#endif
+#define QPWC_FLOW_CHAIN_PRIO() do { if (QPWC_FLOW_PRIO > 0) __builtin_amdgcn_s_setprio(QPWC_FLOW_PRIO); } while (0)
+
 // Blocks are dealt round-robin over the XCDs (block b and b+8 share one), so
 // give every XCD a contiguous run of tiles: neighbouring tiles share their halo
 // through one L2.  Bijective for any grid size; affects speed only.

@@ -288,6 +288,7 @@ template <typename T, int CPL, int KS, int WPB>
 __global__ __launch_bounds__(64 * WPB, 4) void cost_volume_mfma_kernel(
     const T* __restrict__ prv, const T* __restrict__ nxt, T* __restrict__ out, int H, int W, int C,
     int tiles_x, int tiles_y, int n_tiles, int out_pix_stride, float slope, float inv_c, int pad84) {
+    QPWC_FLOW_CHAIN_PRIO();
     constexpr int G = WPB / KS;       // tiles per workgroup
     constexpr int CSTEP = 4 * CPL;    // channels consumed per load step
     constexpr int ES = sizeof(T);
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfm
     const float* __restrict__ prv, const float* __restrict__ nxt, const float* __restrict__ flo,
     float* __restrict__ out, int H, int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope,
     float inv_c, int pad84) {
+    QPWC_FLOW_CHAIN_PRIO();
     __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytes];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -52,6 +52,7 @@ template <typename T, bool ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* __restrict__ weight,
                                                         T* __restrict__ out, int H, int W, int C,
                                                         int strips, int wq, int rows) {
+    QPWC_FLOW_CHAIN_PRIO();
     const int64_t rowthreads = (int64_t)wq * C;  // (x-quad, channel) pairs of one row
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rowthreads) return;
@@ -330,6 +331,7 @@ template <int F, bool ACT, bool VEC, bool ACT_OUT>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     DwSrc src, const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y, int slices) {
+    QPWC_FLOW_CHAIN_PRIO();
     // F = output channels of THIS workgroup.  slices > 1 (coarse levels: few tiles, many 32-channel steps): the
     // layer's slices * F outputs are split over `slices` workgroups per tile -- each repeats the (cheap)
     // depthwise convolution and takes 1 / slices of the matrix work, and the launch has slices x more
@@ -1037,6 +1039,7 @@ __global__ __launch_bounds__(256, 2) void flow_head_kernel(const T* __restrict__
                                                            T* __restrict__ out, int H, int W,
                                                            int tiles_x, int tiles_y, float scale,
                                                            int out_nchw) {
+    QPWC_FLOW_CHAIN_PRIO();
     constexpr int TW = kFhTile + 2;
     constexpr int NH = TW * TW;                                        // 324 halo pixels
     __shared__ __attribute__((aligned(16))) float hs[(NH + 12) * kFhC];  // 21 groups of 16 pixels
@@ -1215,6 +1218,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restrict__ in,
                                                               T* __restrict__ out, int B, int h,
                                                               int w, float scale, int in_nchw, int out_nchw) {
+    QPWC_FLOW_CHAIN_PRIO();
     const int H = 2 * h, W = 2 * w;
     const int64_t total = (int64_t)B * H * W;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void warp_nhwc_vec4_kernel(const T* __restrict
                                                              const float* __restrict__ flo,
                                                              T* __restrict__ out, int B, int H,
                                                              int W, int C, FloStrides fs) {
+    QPWC_FLOW_CHAIN_PRIO();
     const int nch = C >> 2;
     const int64_t total = (int64_t)B * H * W * nch;
     // two independent items per thread and trip: 2 flow reads, then 8 corner gathers in flight
