@@ -332,7 +332,8 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
         mfma_fused = non_layers.fused_front_end_applies(prv, flo)
         out["warp_cost_volume_fused"] = hbm_block(
             "fused WarpV2+cost volume L4 {}".format("x".join(map(str, lvl4))),
-            "cost_volume_mfma_lds_kernel<true>" if mfma_fused else "cost_volume_tiled_kernel<fused>",
+            ("cost_volume_mfma_lds_kernel<true>" if dtype == "f32" else "cost_volume_mfma_lds_f16_kernel<true>")
+            if mfma_fused else "cost_volume_tiled_kernel<fused>",
             unf, f_ms, "warp_cost_volume_L4_bytes_per_launch",
             {"used_by_the_step_at_L4": fused4, "unfused_pair_ms": cv_ms + w_ms,
              "algorithmic_bytes_basis": "unfused pair: cost volume B*H*W*(2C+81)*e + warp B*H*W*(2C+2)*e (SURVEY 8(d))",
@@ -474,7 +475,7 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
             "epe_payload": ("written by the captured EPE reduction (two graphs over one memory pool, replayed "
                             "alternately; no per-step copy)" if graphs is not None and in_place else "copied per step"),
             # levels L1..L4 whose UpFlow runs WarpV2 + cost volume as one launch
-            "fused_upflow": [bool(u.fused) and tdtype == torch.float32 and
+            "fused_upflow": [bool(u.fused) and
                              B * (((hw[0] >> (4 - i)) + 7) // 8) * (((hw[1] >> (4 - i)) + 7) // 8) >= 256
                              for i, u in enumerate(model.upflows)],
             "hip_optflow": True,

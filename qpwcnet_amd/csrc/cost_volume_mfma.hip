@@ -678,9 +678,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int kRegStageBytesH = kRegBlocks * 1024;
 constexpr int kRegLdsBytesH = kRegStageBytesH > 4 * kFrameFloats * 4 ? kRegStageBytesH : 4 * kFrameFloats * 4;
 
-__global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
-    const __half* __restrict__ prv, const __half* __restrict__ nxt, __half* __restrict__ out, int H,
-    int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope, float inv_c, int pad84) {
+// WARP: the fused UpFlow front end as in the fp32 kernel -- a nxt piece is the bilinear blend (fp32 arithmetic on
+// the fp16 corner chunks, ONE rounding to fp16: exactly what the fp16-storage WarpV2 kernel stores) of four
+// corner chunks; taps computed once per pixel by one of its four lanes and exchanged through the wave's own 1 KB.
+template <bool WARP>
+__global__ __launch_bounds__(256, WARP ? 3 : 4) void cost_volume_mfma_lds_f16_kernel(
+    const __half* __restrict__ prv, const __half* __restrict__ nxt, const float* __restrict__ flo,
+    __half* __restrict__ out, int H, int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope,
+    float inv_c, int pad84) {
     __shared__ __attribute__((aligned(16))) char smem[kRegLdsBytesH];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -714,6 +719,34 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
         goff[it] = (x >= 0 && x < W) ? (unsigned)((y * W + x) * C * 2 + sc * 16) : kOob;
     }
 
+    // ---- WARP: corner (y0, x0) byte offset + chunk and the lerp factors of the four nxt pieces ----
+    float wax[WARP ? 4 : 1], way[WARP ? 4 : 1];
+    const unsigned pixb = (unsigned)C * 2u, rowb2 = (unsigned)W * pixb;
+    if (WARP) {
+        const int blk = 4 * sc + wave;   // this lane's share: piece it = sc
+        const int yy = Y0 - 4 + 4 * (blk >> 2) + spy, xx = X0 - 4 + 4 * (blk & 3) + spx;
+        const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float2 f = make_float2(0.f, 0.f);
+        if (inside) f = *reinterpret_cast<const float2*>(flo + ((int64_t)(b * H + yy) * W + xx) * 2);
+        const Taps t = taps_clamp(yy, xx, f.x, f.y, H, W);
+        uint4 rec;
+        rec.x = inside ? (unsigned)(t.y0 * W + t.x0) * pixb : kOob;
+        rec.y = __float_as_uint(t.ax);
+        rec.z = __float_as_uint(t.ay);
+        rec.w = 0u;
+        char* xch = smem + wave * 1024 + (lane >> 2) * 64;   // 4 records of the lane group
+        *reinterpret_cast<uint4*>(xch + sc * 16) = rec;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint4 r = *reinterpret_cast<const uint4*>(xch + it * 16);
+            goff[it] = r.x + (unsigned)sc * 16u;
+            wax[it] = __uint_as_float(r.y);
+            way[it] = __uint_as_float(r.z);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
     const int n = lane & 15, g = lane >> 4;
     const int ti = wave >> 1, tj = wave & 1;
     const int coff = n * 64 + ((g ^ ((n >> 2) & 2)) << 4);
@@ -729,9 +762,42 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
     for (int s = 0; s < nsteps; ++s) {
         const int soff = s * 64;
         u32x4 st[5];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
         st[4] = __builtin_amdgcn_raw_buffer_load_b128(rp, goff[4], soff, 0);
+        if (WARP) {
+            // two pieces per round: 8 corner chunks (8 halves each) in flight
+#pragma unroll
+            for (int it = 0; it < 4; it += 2) {
+                u32x4 c[2][4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned o = goff[it + q];
+                    c[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff, 0);
+                    c[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)pixb, 0);
+                    c[q][2] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)rowb2, 0);
+                    c[q][3] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)(rowb2 + pixb), 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    Taps t;
+                    t.ax = wax[it + q];
+                    t.ay = way[it + q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // one 32-bit word = two halves
+                        float tl0, tl1, tr0, tr1, bl0, bl1, br0, br1;
+                        unpack_half2(c[q][0][e], tl0, tl1);
+                        unpack_half2(c[q][1][e], tr0, tr1);
+                        unpack_half2(c[q][2][e], bl0, bl1);
+                        unpack_half2(c[q][3][e], br0, br1);
+                        const __half2 h = __floats2half2_rn(blend<QPWC_WARP_CLAMP>(t, tl0, tr0, bl0, br0),
+                                                            blend<QPWC_WARP_CLAMP>(t, tl1, tr1, bl1, br1));
+                        st[it + q][e] = *reinterpret_cast<const unsigned*>(&h);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goff[it], soff, 0);
+        }
         if (s > 0) __syncthreads();
 #pragma unroll
         for (int it = 0; it < 5; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 4096) = st[it];
@@ -763,8 +829,8 @@ __global__ __launch_bounds__(256, 4) void cost_volume_mfma_lds_f16_kernel(
     store_tile<__half>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab, pad84 != 0);
 }
 
-static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int B, int H, int W, int C,
-                          int64_t ops, float slope, int pad84, hipStream_t s) {
+static int launch_lds_f16(const __half* prv, const __half* nxt, const float* flo, __half* out, int B, int H, int W,
+                          int C, int64_t ops, float slope, int pad84, hipStream_t s) {
     const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
     const int64_t nblk = (int64_t)regs_x * regs_y * B;
     if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * 2 >= 0x7fffffff ||
@@ -773,8 +839,13 @@ static int launch_lds_f16(const __half* prv, const __half* nxt, __half* out, int
         return QPWC_E_SHAPE;
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
-    hipLaunchKernelGGL(cost_volume_mfma_lds_f16_kernel, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
-                       out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
+    if (flo) {
+        hipLaunchKernelGGL(cost_volume_mfma_lds_f16_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, flo,
+                           out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
+        return check_launch("cost_volume_mfma_lds_f16_kernel<warp>");
+    }
+    hipLaunchKernelGGL(cost_volume_mfma_lds_f16_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
+                       (const float*)nullptr, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_lds_f16_kernel");
 }
 
@@ -873,7 +944,7 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, const void* flo, v
     if (pads_written) *pads_written = false;
     if (C % 16 != 0 || (reinterpret_cast<uintptr_t>(prv) | reinterpret_cast<uintptr_t>(nxt)) % 16)
         return 1;
-    if (flo && (dtype != QPWC_F32 || C % 32 != 0 || reinterpret_cast<uintptr_t>(flo) % 8 || H < 2 || W < 2 ||
+    if (flo && (C % 32 != 0 || reinterpret_cast<uintptr_t>(flo) % 8 || H < 2 || W < 2 ||
                 (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B < 256))
         return 1;
     // 32-bit byte offsets inside one image (buffer descriptors) and 32-bit element offsets
@@ -902,7 +973,8 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, const void* flo, v
     if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 256 && lds_mode() != 0) {
         if (pads_written)   // dense 8-byte rows of 4 px x 84 halves
             *pads_written = pad84 && W % 4 == 0 && H % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
-        return launch_lds_f16((const __half*)prv, (const __half*)nxt, (__half*)out, B, H, W, C, ops, slope, pad84, s);
+        return launch_lds_f16((const __half*)prv, (const __half*)nxt, (const float*)flo, (__half*)out, B, H, W, C, ops,
+                              slope, pad84, s);
     }
     if (C % 32 == 0)
         return dispatch_mfma<__half, 8>((const __half*)prv, (const __half*)nxt, (__half*)out, B, H,

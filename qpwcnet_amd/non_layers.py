@@ -520,12 +520,11 @@ def _cost84(prv, nxt, search_range, flo=None):
 
 def fused_front_end_applies(prv, flo, search_range=4):
     """True where qpwc_warp_cost_volume_fwd runs on the matrix cores (WarpV2 gathered in the staging step of
-    the workgroup-shared cost-volume kernel): channels-last fp32, C % 32 == 0, >= 256 regions of 8 x 8
+    the workgroup-shared cost-volume kernel): channels-last fp32 or fp16 storage, C % 32 == 0, >= 256 regions of 8 x 8
     pixels -- the same rule as cost_volume_mfma_launch.  tools/kbench.py, B=8: L2 14.4 vs 10.5 + 8.1 us for
     warp + cost volume, L3 25.9 vs 17.9 + 9.6, L4 48.3 vs 36.1 + 16.9.  Elsewhere (few regions: the per-wave
     split-K kernel's territory) two launches are faster than the LDS-tiled vector kernel's fused form."""
-    if not (prv.is_cuda and prv.dtype == torch.float32 and prv.dim() == 4 and search_range == 4 and
-            flo.dtype == torch.float32):
+    if not (prv.is_cuda and prv.dtype in (torch.float32, torch.float16) and prv.dim() == 4 and search_range == 4):
         return False
     B, H, W, C = prv.shape
     return C % 32 == 0 and H >= 2 and W >= 2 and B * ((H + 7) // 8) * ((W + 7) // 8) >= 256
@@ -553,10 +552,11 @@ class UpFlow(_Weighted):
         prv, nxt, flo = inputs
         r = self.cost_volume.search_range
         if self.fused and fused_front_end_applies(prv, flo, r):
+            flo32 = flo.to(torch.float32).contiguous()   # coordinates are fp32 whatever the storage dtype
             if self.flow.wants_cost84(prv):
-                cost = _cost84(prv, nxt, r, flo=flo.contiguous())
+                cost = _cost84(prv, nxt, r, flo=flo32)
             else:
-                cost = ops.warp_cost_volume(prv.contiguous(), nxt.contiguous(), flo.contiguous(), r, 0.1)
+                cost = ops.warp_cost_volume(prv.contiguous(), nxt.contiguous(), flo32, r, 0.1)
             return self.flow.from_sources((cost, prv, flo))
         nxt_w = self.warp((nxt, flo))
         if self.hip_optflow and self.flow.wants_cost84(prv):
