@@ -518,7 +518,7 @@ def _cost84(prv, nxt, search_range, flo=None):
     return cost
 
 
-def fused_front_end_applies(prv, flo, search_range=4):
+def fused_front_end_applies(prv, flo=None, search_range=4):
     """True where qpwc_warp_cost_volume_fwd runs on the matrix cores (WarpV2 gathered in the staging step of
     the workgroup-shared cost-volume kernel): channels-last fp32 or fp16 storage, C % 32 == 0, >= 256 regions of 8 x 8
     pixels -- the same rule as cost_volume_mfma_launch.  tools/kbench.py, B=8: L2 14.4 vs 10.5 + 8.1 us for

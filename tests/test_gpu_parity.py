@@ -350,6 +350,43 @@ def test_matrix_core_kernels_ragged_edges(shape):
     np.testing.assert_allclose(outh, refh, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("shape", [(32, 36, 52, 32), (40, 30, 44, 64), (20, 33, 47, 128), (8, 128, 256, 32)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_fused_front_end_on_the_matrix_cores_ragged_edges_and_far_flows(shape, dtype):
+    """qpwc_warp_cost_volume_fwd where the workgroup-shared matrix-core kernel takes it (>= 256 regions, C % 32 == 0):
+    H, W not multiples of the 8 x 8 region, flows that leave the image on every side (clamp-to-border taps) and
+    land exactly on the last row / column; every output form (dense 81, 84 with zero pads, strided into a concat
+    buffer).  The gather blends with the WarpV2 kernel's own code: the result must equal warp -> cost volume bit for
+    bit, and the C oracle within the fp32 / fp16-rounding bound."""
+    assert non_layers.fused_front_end_applies(torch.empty(shape, device=DEV, dtype=dtype), None)
+    B, H, W, C = shape
+    g = torch.Generator(device=DEV).manual_seed(H * W + C)
+    prv = torch.randn(*shape, device=DEV, generator=g).to(dtype)
+    nxt = torch.randn(*shape, device=DEV, generator=g).to(dtype)
+    flo = torch.randn(B, H, W, 2, device=DEV, generator=g) * 6
+    flo[:, :2] = 40.0                      # far below / right of the image
+    flo[:, -2:] = -40.0                    # far above / left
+    flo[:, 5, :, 0] = (W - 1) - torch.arange(W, device=DEV, dtype=torch.float32)   # exactly the last column
+    flo[:, 5, :, 1] = float(H - 1 - 5)                                             # ... of the last row
+    flo[:, 7] = 0.0
+    unf = ops.cost_volume(prv, ops.warp(nxt, flo, "clamp"))
+    dense = ops.warp_cost_volume(prv, nxt, flo)
+    assert torch.equal(dense, unf)
+    pad = torch.full((B, H, W, 84), float("nan"), device=DEV, dtype=dtype)
+    ops.cost_volume_into(prv, nxt, pad, 0, flo=flo)
+    assert torch.equal(pad[..., :81], unf) and float(pad[..., 81:].abs().max()) == 0.0
+    wide = torch.full((B, H, W, 81 + C + 2), 7.0, device=DEV, dtype=dtype)
+    ops.cost_volume_into(prv, nxt, wide, 0, flo=flo)
+    assert torch.equal(wide[..., :81], unf) and bool((wide[..., 81:] == 7.0).all())
+    sub = [0, B - 1]
+    p32, n32, f32 = (t[sub].float().cpu().numpy() for t in (prv, nxt, flo))
+    ref = c_ref.cost_volume(p32, c_ref.warp(n32, f32).astype(np.float16 if dtype == torch.float16 else np.float32)
+                            .astype(np.float32))
+    got = dense[sub].float().cpu().numpy()
+    tol = TOL if dtype == torch.float32 else TOL + 2.0 ** -11 * np.abs(ref)
+    assert np.all(np.abs(got - ref) <= tol)
+
+
 @pytest.mark.parametrize("shape", [(16, 64, 64, 32), (2, 16, 32, 64)])
 def test_matrix_core_kernels_strided_output(shape):
     """81 channels written at a channel offset of a wider buffer (the concat target)."""
