@@ -100,6 +100,8 @@ class QpwcNet:
         self.batch_frames = bool(batch_frames)
         self.overlap_streams = bool(overlap_streams)
         self._side = None
+        # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
+        self.dec_chunks = (2, 4, 4, 4)
         self.input_shape = tuple(input_shape)
         self.device = torch.device(device)
         self.dtype = dtype
@@ -225,7 +227,7 @@ class QpwcNet:
         with torch.cuda.stream(side):
             f, i = encs[-1], -2
             for li, l in enumerate(self.dec):
-                hip_chunks = (2 if li == 0 else 4) if small else 1
+                hip_chunks = self.dec_chunks[li] if small else 1
                 f = l.cat_skip(f, encs[i], batch_chunks=chunks, hip_chunks=hip_chunks)
                 i -= 1
                 # allocated on `side`, read by UpFlow on `main`: tell the caching allocator, so that the block
