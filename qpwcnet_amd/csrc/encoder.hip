@@ -47,96 +47,145 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
     return C == 16 ? (q ^ ((hp >> 2) & 3)) : (q ^ ((hp >> 1) & (C / 4 - 1)));
 }
 
-template <int C>
+// NT > 1 (A/B: make ab ABSRC=encoder ABFLAGS=-DQPWC_ENC_NT=2): the workgroup walks NT x-adjacent tiles with a
+// double-buffered halo image: the loads of tile t + 1 are issued before the matrix work of tile t and written to
+// the other LDS buffer after its epilogue (one barrier per tile), so that only the first load and the last store of
+// a workgroup are exposed.  Measured in one call (round 2; 66 / 104 registers once the lane offsets are kept from
+// being hoisted out of the tile loop): C = 16 34.0 (NT 1) / 36.9 (2) / 37.1 (4) us, C = 32 30.5 / 33.4 / 38.6 --
+// slower, like round 1's register-heavier attempt: fewer, longer-lived workgroups lose more than the hidden loads
+// win.  The product build is NT = 1.
+#ifndef QPWC_ENC_NT
+#define QPWC_ENC_NT 1
+#endif
+template <int C, int NT>
 __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ weight,
                                                               const float* __restrict__ bias,
                                                               float* __restrict__ out, int H, int W,
-                                                              int pad_h, int pad_w, int tiles_x, int tiles_y) {
+                                                              int pad_h, int pad_w, int tiles_x, int tiles_y,
+                                                              int groups_x) {
     constexpr int NQ = C / 4;     // 16-byte chunks per pixel
     constexpr int NFT = C / 16;   // output blocks of 16 channels
     constexpr int NKC = C / 16;   // 16-channel k chunks
-    __shared__ __attribute__((aligned(16))) float in_s[kEcNH * C];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int X0 = tx * kEcTW, Y0 = ty * kEcTH;
+    constexpr int NLD = (kEcNH * NQ + 255) / 256;   // staging loads per thread and tile
+    constexpr int NBUF = NT > 1 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float in_s[NBUF * kEcNH * C];
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int lane = tid0 & 63, n0 = lane & 15, g0 = lane >> 4;
+    const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int gx0 = grp % groups_x, ty = (grp / groups_x) % tiles_y, b = grp / (groups_x * tiles_y);
+    const int tx0 = gx0 * NT;
+    const int Y0 = ty * kEcTH;
     const float* xb = x + (int64_t)b * H * W * C;
-
-    // ---- stage the halo tile (zero outside the image) ----
-    for (int idx = tid; idx < kEcNH * NQ; idx += 256) {
-        const int hp = idx / NQ, q = idx - hp * NQ;
-        const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
-        const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)gy * W + gx) * C + 4 * q);
-        const int slot = ec_slot<C>(q, hp);
-        *reinterpret_cast<float4*>(in_s + hp * C + 4 * slot) = v;
-    }
-    __syncthreads();
-
     const int Ho = H + pad_h, Wo = W + pad_w;
     float* ob = out + (int64_t)b * Ho * Wo * C;
+
+    auto stage_load = [&](int tid, int tx, float4 (&v)[NLD]) {
+        const int X0 = tx * kEcTW;
 #pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) {
-        // weights of output block ft for this lane: row f = 16 ft + n, channels 16 kc + 4g .. + 3, 9 taps
-        f32x4e wv[9][NKC];
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            v[it] = (idx < kEcNH * NQ && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                        ? *reinterpret_cast<const float4*>(xb + ((int64_t)gy * W + gx) * C + 4 * q)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage_write = [&](int tid, int buf, const float4 (&v)[NLD]) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            if (idx < kEcNH * NQ)
+                *reinterpret_cast<float4*>(in_s + buf * (kEcNH * C) + hp * C + 4 * ec_slot<C>(q, hp)) = v[it];
+        }
+    };
+    float4 st[NLD];
+    stage_load(tid0, tx0, st);
+    stage_write(tid0, 0, st);
+    __syncthreads();
+
+#pragma unroll 1   // a real loop: unrolled, the compiler hoists the next tiles' weight loads (73 / 102 registers at NT = 2 / 4)
+    for (int t = 0; t < NT; ++t) {
+        const int tx = tx0 + t;
+        if (tx >= tiles_x) break;                      // workgroup-uniform
+        const bool more = t + 1 < NT && tx + 1 < tiles_x;
+
+        const int X0 = tx * kEcTW;
+        const float* tile_s = in_s + (t & (NBUF - 1)) * (kEcNH * C);
+        // the weights are re-read per tile (L1 hits): hoisted out of the tile loop they would stay live across
+        // it (36 / 144 registers) -- the opaque copy of the pointer keeps the loads inside
+        const float* wt = weight;
+        int n = n0, g = g0, tid = tid0;
+        if (NT > 1) asm volatile("" : "+r"(wt), "+v"(n), "+v"(g), "+v"(tid));   // and the lane offsets derived from these
+        if (more) stage_load(tid, tx + 1, st);         // in flight behind this tile's matrix work
 #pragma unroll
-            for (int kc = 0; kc < NKC; ++kc)
-                wv[k][kc] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)k * C + 16 * ft + n) * C + 16 * kc + 4 * g);
-        f32x4e acc[2];
-        acc[0] = f32x4e{0.f, 0.f, 0.f, 0.f};
-        acc[1] = f32x4e{0.f, 0.f, 0.f, 0.f};
+        for (int ft = 0; ft < NFT; ++ft) {
+            // weights of output block ft for this lane: row f = 16 ft + n, channels 16 kc + 4g .. + 3, 9 taps
+            f32x4e wv[9][NKC];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+                for (int kc = 0; kc < NKC; ++kc)
+                    wv[k][kc] = *reinterpret_cast<const f32x4e*>(wt + ((int64_t)k * C + 16 * ft + n) * C + 16 * kc + 4 * g);
+            f32x4e acc[2];
+            acc[0] = f32x4e{0.f, 0.f, 0.f, 0.f};
+            acc[1] = f32x4e{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc) {
-                    f32x4e bv[2];
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const int hp = (2 * wave + m + ky) * kEcHW + n + kx;
-                        const int q = 4 * kc + g;
-                        const int slot = ec_slot<C>(q, hp);
-                        bv[m] = *reinterpret_cast<const f32x4e*>(in_s + hp * C + 4 * slot);
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        f32x4e bv[2];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const int hp = (2 * wave + m + ky) * kEcHW + n + kx;
+                            const int q = 4 * kc + g;
+                            const int slot = ec_slot<C>(q, hp);
+                            bv[m] = *reinterpret_cast<const f32x4e*>(tile_s + hp * C + 4 * slot);
+                        }
+                        // alternate the two accumulators: a dependent matrix instruction issued back to back
+                        // waits 40 cycles instead of 32
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][tt], bv[m][tt], acc[m], 0, 0, 0);
                     }
-                    // alternate the two accumulators: a dependent matrix instruction issued back to back
-                    // waits 40 cycles instead of 32
+            // ---- bias + Mish: lane = pixel n of tile row 2 wave + m, outputs 16 ft + 4g .. + 3 ----
+            const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[m][t], acc[m], 0, 0, 0);
-                }
-        // ---- bias + Mish: lane = pixel n of tile row 2 wave + m, outputs 16 ft + 4g .. + 3 ----
-        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int gy = Y0 + 2 * wave + m, gx = X0 + n;
-            if (gy < H && gx < W)
-                *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * C + 16 * ft + 4 * g) =
-                    make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
-                                enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
+            for (int m = 0; m < 2; ++m) {
+                const int gy = Y0 + 2 * wave + m, gx = X0 + n;
+                if (gy < H && gx < W)
+                    *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * C + 16 * ft + 4 * g) =
+                        make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
+                                    enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
+            }
         }
-    }
-    // ---- zero border of the padded output (columns W.., rows H..), written by the edge tiles ----
-    if (pad_w > 0 && X0 + kEcTW >= W) {
-        for (int i = tid; i < kEcTH * pad_w * NQ; i += 256) {
-            const int q = i % NQ, r = i / NQ, col = r % pad_w, row = r / pad_w;
-            const int gy = Y0 + row;
-            if (gy < H) *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + W + col) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ---- zero border of the padded output (columns W.., rows H..), written by the edge tiles ----
+        if (pad_w > 0 && X0 + kEcTW >= W) {
+            for (int i = tid; i < kEcTH * pad_w * NQ; i += 256) {
+                const int q = i % NQ, r = i / NQ, col = r % pad_w, row = r / pad_w;
+                const int gy = Y0 + row;
+                if (gy < H) *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + W + col) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-    }
-    if (pad_h > 0 && Y0 + kEcTH >= H) {
-        const int x_end = (X0 + kEcTW >= W) ? Wo : X0 + kEcTW;   // the corner belongs to the last tile
-        for (int i = tid; i < pad_h * (x_end - X0) * NQ; i += 256) {
-            const int q = i % NQ, r = i / NQ, col = r % (x_end - X0), row = r / (x_end - X0);
-            *reinterpret_cast<float4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pad_h > 0 && Y0 + kEcTH >= H) {
+            const int x_end = (X0 + kEcTW >= W) ? Wo : X0 + kEcTW;   // the corner belongs to the last tile
+            for (int i = tid; i < pad_h * (x_end - X0) * NQ; i += 256) {
+                const int q = i % NQ, r = i / NQ, col = r % (x_end - X0), row = r / (x_end - X0);
+                *reinterpret_cast<float4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (more) {
+            // buffer (t + 1) & 1 was last read by tile t - 1, whose waves all passed the previous barrier
+            stage_write(tid, (t + 1) & (NBUF - 1), st);
+            __syncthreads();
         }
     }
 }
@@ -736,18 +785,20 @@ int conv3x3s2_mish_any_launch(const void* x, const void* weight, const void* bia
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s) {
     const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + kEcTH - 1) / kEcTH;
-    const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
+    constexpr int NT = QPWC_ENC_NT;
+    const int groups_x = (tiles_x + NT - 1) / NT;
+    const int64_t nblk = (int64_t)groups_x * tiles_y * B;
     if (nblk > INT32_MAX) {
         set_error("conv3x3_mish: too many tiles");
         return QPWC_E_SHAPE;
     }
     const dim3 grid((unsigned)nblk);
     if (C == 16)
-        hipLaunchKernelGGL(conv3x3_mish_kernel<16>, grid, dim3(256), 0, s, (const float*)x, (const float*)weight,
-                           (const float*)bias, (float*)out, H, W, pad_h, pad_w, tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv3x3_mish_kernel<16, NT>), grid, dim3(256), 0, s, (const float*)x, (const float*)weight,
+                           (const float*)bias, (float*)out, H, W, pad_h, pad_w, tiles_x, tiles_y, groups_x);
     else if (C == 32)
-        hipLaunchKernelGGL(conv3x3_mish_kernel<32>, grid, dim3(256), 0, s, (const float*)x, (const float*)weight,
-                           (const float*)bias, (float*)out, H, W, pad_h, pad_w, tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv3x3_mish_kernel<32, NT>), grid, dim3(256), 0, s, (const float*)x, (const float*)weight,
+                           (const float*)bias, (float*)out, H, W, pad_h, pad_w, tiles_x, tiles_y, groups_x);
     else if (C == 64)
         return conv3x3_mish_wide_launch<64, 4>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
     else if (C == 128)
