@@ -205,6 +205,18 @@ int qpwc_flow_head_param_floats(void);
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W,
                        float scale, int dtype, int out_layout, void* stream);
 
+/* The tail of OptFlow.__call__ in one launch, for small images (coarse pyramid levels), fp32 channels-last:
+ *   z3   = Mish(SeparableConv2D_3(z2))    64 -> 32   (non_layers.py:223-231, third of the four)
+ *   z4   = SeparableConv2D_4(z3)          32 -> 16
+ *   flow = scale * conv3x3( BN( Mish( W1 * Mish(z4) + b1 ) ) )   (non_layers.py:238-254, 268-273)
+ * z2: (B,H,W,64), the second SeparableConv2D's output, ALREADY Mish-activated (mish_on_load = 0) or
+ * pre-activation (mish_on_load = 1).  dw3 (64,9), pw3 (32,64) row-major, b3 (32); dw4 (32,9), pw4 (16,32), b4 (16);
+ * head_params as qpwc_flow_head_fwd.  out: (B,H,W,2) / (B,2,H,W) by out_layout.  Same arithmetic as
+ * qpwc_sepconv3x3_fwd x 2 + qpwc_flow_head_fwd (fp32 matrix cores for the pointwise parts). */
+int qpwc_optflow_tail_fwd(const void* z2, const void* dw3, const void* pw3, const void* b3, const void* dw4,
+                          const void* pw4, const void* b4, const void* head_params, void* out, int B, int H, int W,
+                          float scale, int mish_on_load, int out_layout, void* stream);
+
 /* x = Mish(x + bias[c]) in place, channels-last fp32 (n_pixels, C), C % 4 == 0, bias may
  * be NULL: the `activation='Mish'` epilogue of the reference's Conv2D / Conv2DTranspose /
  * SeparableConv2D blocks (non_layers.py:196-210, 223-231, 390-449; mish.py:27-28). */

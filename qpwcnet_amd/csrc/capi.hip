@@ -54,6 +54,9 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      int dtype, int out_layout, hipStream_t s);
 int flow_head_param_floats();
+int optflow_tail_launch(const void* z2, const void* dw3, const void* pw3, const void* b3, const void* dw4,
+                        const void* pw4, const void* b4, const void* head, void* out, int B, int H, int W,
+                        float scale, int act_in, int out_layout, hipStream_t s);
 int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, int dtype,
                            int in_layout, int out_layout, hipStream_t s);
 int bias_mish_pad_launch(const void* src, const void* bias, void* dst, int B, int H, int W, int C,
@@ -355,6 +358,22 @@ int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int 
     if (overlaps(out, (size_t)B * H * W * 2 * es, z, (size_t)B * H * W * 16 * es))
         return fail(QPWC_E_ALIAS, "out overlaps z");
     return flow_head_launch(z, params, out, B, H, W, scale, dtype, out_layout, (hipStream_t)stream);
+}
+
+int qpwc_optflow_tail_fwd(const void* z2, const void* dw3, const void* pw3, const void* b3, const void* dw4,
+                          const void* pw4, const void* b4, const void* head_params, void* out, int B, int H, int W,
+                          float scale, int mish_on_load, int out_layout, void* stream) {
+    if (!z2 || !dw3 || !pw3 || !b3 || !dw4 || !pw4 || !b4 || !head_params || !out)
+        return fail(QPWC_E_NULL, "null pointer argument");
+    if (out_layout != QPWC_NHWC && out_layout != QPWC_NCHW)
+        return fail(QPWC_E_LAYOUT, "Unsupported data format : %d", out_layout);
+    if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
+    if ((uintptr_t)z2 % 16 || (uintptr_t)pw3 % 16 || (uintptr_t)pw4 % 16 || (uintptr_t)b3 % 16 || (uintptr_t)b4 % 16 ||
+        (uintptr_t)head_params % 16 || (uintptr_t)dw3 % 4 || (uintptr_t)dw4 % 4 || (uintptr_t)out % 8)
+        return fail(QPWC_E_ALIGN, "z2, pw3, pw4, b3, b4, head_params must be 16-byte aligned, out 8-byte");
+    if (overlaps(out, (size_t)B * H * W * 2 * 4, z2, (size_t)B * H * W * 64 * 4)) return fail(QPWC_E_ALIAS, "out overlaps z2");
+    return optflow_tail_launch(z2, dw3, pw3, b3, dw4, pw4, b4, head_params, out, B, H, W, scale, mish_on_load,
+                               out_layout, (hipStream_t)stream);
 }
 
 int qpwc_bias_mish_fwd(void* x, const void* bias, int64_t n_pixels, int C, int dtype, void* stream) {

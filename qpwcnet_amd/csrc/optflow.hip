@@ -1308,6 +1308,309 @@ int split_frames_pad_launch(const void* in, void* out, int B, int H, int W, int 
     return check_launch("split_frames_pad_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// optflow_tail: the last two SeparableConv2D (64 -> 32 -> 16), the flow head and the scale of OptFlow
+// (qpwcnet/core/non_layers.py:223-231, 238-254, 268-273) in ONE launch, for the coarse pyramid levels.
+//
+// There the four launches it replaces (two fused SeparableConv2D, flow head; 5-16 us each in the step, next to the
+// decoder's chip-filling launches) are bound by their own start-up latency, not by their work.  A workgroup owns
+// an 8 x 8 pixel tile of the flow and recomputes the halo every 3x3 stage needs: z2 (input, 64 channels,
+// Mish-activated by its producer) on 14 x 14 pixels -> z3 = Mish(sepconv3) on 12 x 12 -> z4 = sepconv4 on 10 x 10
+// -> h = BN(Mish(W1 Mish(z4) + b1)) on 10 x 10 -> flow = scale * conv3x3(h) on 8 x 8.  2.25 x the matrix work of
+// the first of those layers -- irrelevant at these sizes -- for one prologue instead of four.
+// Every intermediate is ZERO outside the image (Keras 'same' padding pads each layer's input).
+//   phase A (2 steps of 32 input channels): stage z2 -> depthwise 3x3 (thread = 4 channels x 5 pixels) -> y3 ->
+//            pointwise on the matrix cores, rows = outputs, cols = 16 pixels (9 groups x 2 output blocks over 4 waves)
+//   phase B: depthwise 3x3 on z3 -> y4 -> pointwise 32 -> 16 (7 pixel groups)
+//   phase C: the accumulator layout (pixel n, outputs 4g..4g+3) IS the next operand layout: Mish, W1 on the matrix
+//            cores, Mish, BatchNorm, to LDS
+//   phase D: 3x3 conv 16 -> 2 as in flow_head_kernel (lane = pixel x channel quad, two wave shuffles)
+// LDS 80 KB (fits beside one of the decoder's 74 KB workgroups): z2 tile (pixel stride 40 floats) | y3 | z3 (stride
+// 40) | weights; y4 aliases the z2 tile, h aliases y3.
+constexpr int kTlT = 8;                                  // flow tile
+constexpr int kTlR2 = kTlT + 6, kTlR3 = kTlT + 4, kTlR4 = kTlT + 2;
+constexpr int kTlN2 = kTlR2 * kTlR2, kTlN3 = kTlR3 * kTlR3, kTlN4 = kTlR4 * kTlR4;   // 196, 144, 100 pixels
+constexpr int kTlG3 = kTlN3 / 16, kTlG4 = (kTlN4 + 15) / 16;                          // 9, 7 pixel groups
+constexpr int kTlPS = 40;                                // floats per pixel of the depthwise inputs
+
+template <bool ACT_IN>
+__global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
+    const float* __restrict__ z2, const float* __restrict__ dw3, const float* __restrict__ pw3,
+    const float* __restrict__ b3, const float* __restrict__ dw4, const float* __restrict__ pw4,
+    const float* __restrict__ b4, const float* __restrict__ head, float* __restrict__ out, int H, int W,
+    int tiles_x, int tiles_y, float scale, int out_nchw) {
+    QPWC_FLOW_CHAIN_PRIO();
+    __shared__ __attribute__((aligned(16))) float in_s[kTlN2 * kTlPS];          // z2 tile; later y4 [112][32]
+    __shared__ __attribute__((aligned(16))) float y3_s[kTlN3 * 32];             // y3; later h [112][16]
+    __shared__ __attribute__((aligned(16))) float z3_s[kTlN3 * kTlPS];
+    __shared__ __attribute__((aligned(16))) float w3_s[32 * 32];
+    __shared__ __attribute__((aligned(16))) float w4_s[16 * 32];
+    __shared__ __attribute__((aligned(16))) float dw_s[9 * 32];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4, sw = n >> 1;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kTlT, Y0 = ty * kTlT;
+    const float* zb = z2 + (int64_t)b * H * W * 64;
+    const int cq = tid & 7, pr = tid >> 3;      // depthwise map: channel quad, pixel row of 32
+
+    // pointwise 32 -> 16 weights: 16 rows x 8 chunks, chunk q of row f at q ^ ((f & 15) >> 1)
+    if (tid < 128) {
+        const int f = tid >> 3, q = tid & 7;
+        *reinterpret_cast<float4*>(w4_s + f * 32 + ((q ^ ((f & 15) >> 1)) << 2)) =
+            *reinterpret_cast<const float4*>(pw4 + f * 32 + 4 * q);
+    }
+
+    // ================= phase A: z3 = Mish(pointwise3(depthwise3(z2)) + b3) on the 12 x 12 region ==============
+    f32x4v acc3[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) acc3[i][ft] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+        if (s) __syncthreads();   // the previous step's operand reads are done
+        // ---- stage the 14 x 14 x 32 input tile, the 32 x 32 weight slice and the 32 x 9 depthwise taps ----
+        float4 st[7];
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx >> 3, q = idx & 7;
+            const int gy = Y0 - 3 + hp / kTlR2, gx = X0 - 3 + hp % kTlR2;
+            st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < kTlN2 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                st[it] = *reinterpret_cast<const float4*>(zb + ((int64_t)gy * W + gx) * 64 + 32 * s + 4 * q);
+        }
+        const float4 wr = *reinterpret_cast<const float4*>(pw3 + (tid >> 3) * 64 + 32 * s + 4 * (tid & 7));
+        float dr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            dr[i] = idx < 288 ? dw3[32 * s * 9 + idx] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx >> 3, q = idx & 7;
+            if (hp < kTlN2) {
+                float4 v = st[it];
+                if (ACT_IN) v = make_float4(mishf(v.x), mishf(v.y), mishf(v.z), mishf(v.w));   // mish(0) == 0
+                *reinterpret_cast<float4*>(in_s + hp * kTlPS + 4 * q) = v;
+            }
+        }
+        {
+            const int f = tid >> 3, q = tid & 7;
+            *reinterpret_cast<float4*>(w3_s + f * 32 + ((q ^ ((f & 15) >> 1)) << 2)) = wr;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 288) dw_s[(idx % 9) * 32 + idx / 9] = dr[i];
+        }
+        __syncthreads();
+        // ---- depthwise 3x3 on the 12 x 12 region: thread = channel quad cq, pixels pr + 32 j ----
+        {
+            float4 wq[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wq[k] = *reinterpret_cast<const float4*>(dw_s + k * 32 + 4 * cq);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int p = pr + 32 * j;
+                if (p < kTlN3) {
+                    const int r = p / kTlR3, c = p - r * kTlR3;
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float4 v = *reinterpret_cast<const float4*>(in_s + ((r + ky) * kTlR2 + c + kx) * kTlPS + 4 * cq);
+                            const float4 wk = wq[ky * 3 + kx];
+                            a.x = fmaf(wk.x, v.x, a.x); a.y = fmaf(wk.y, v.y, a.y);
+                            a.z = fmaf(wk.z, v.z, a.z); a.w = fmaf(wk.w, v.w, a.w);
+                        }
+                    *reinterpret_cast<float4*>(y3_s + p * 32 + ((cq ^ ((p & 15) >> 1)) << 2)) = a;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- pointwise: wave w owns pixel groups w, w + 4, w + 8 (< 9), both output blocks ----
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int coff = ((4 * u + g) ^ sw) << 2;
+            f32x4v wv[2];
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) wv[ft] = *reinterpret_cast<const f32x4v*>(w3_s + (16 * ft + n) * 32 + coff);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int grp = wave + 4 * i;
+                if (grp < kTlG3) {   // wave-uniform
+                    const f32x4v yv = *reinterpret_cast<const f32x4v*>(y3_s + (16 * grp + n) * 32 + coff);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ft = 0; ft < 2; ++ft)
+                            acc3[i][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ft][t], yv[t], acc3[i][ft], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- z3 = Mish(acc + b3), zero outside the image, to LDS (pixel stride 40) ----
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int grp = wave + 4 * i;
+        if (grp < kTlG3) {
+            const int p = 16 * grp + n;
+            const int gy = Y0 - 2 + p / kTlR3, gx = X0 - 2 + p % kTlR3;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                const float4 bv = *reinterpret_cast<const float4*>(b3 + 16 * ft + 4 * g);
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) z = make_float4(mishf(acc3[i][ft][0] + bv.x), mishf(acc3[i][ft][1] + bv.y),
+                                        mishf(acc3[i][ft][2] + bv.z), mishf(acc3[i][ft][3] + bv.w));
+                *reinterpret_cast<float4*>(z3_s + p * kTlPS + 16 * ft + 4 * g) = z;
+            }
+        }
+    }
+    // depthwise taps of layer 4
+    {
+        float dr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            dr[i] = idx < 288 ? dw4[idx] : 0.0f;
+        }
+        __syncthreads();   // z3 complete; y3 / w3 / dw_s / in_s free
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 288) dw_s[(idx % 9) * 32 + idx / 9] = dr[i];
+        }
+    }
+    __syncthreads();
+    // ================= phase B: z4 = pointwise4(depthwise4(z3)) + b4 on the 10 x 10 region ==================
+    float* y4_s = in_s;   // [112][32]
+    {
+        float4 wq[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wq[k] = *reinterpret_cast<const float4*>(dw_s + k * 32 + 4 * cq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = pr + 32 * j;
+            if (p < 16 * kTlG4) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < kTlN4) {
+                    const int r = p / kTlR4, c = p - r * kTlR4;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float4 v = *reinterpret_cast<const float4*>(z3_s + ((r + ky) * kTlR3 + c + kx) * kTlPS + 4 * cq);
+                            const float4 wk = wq[ky * 3 + kx];
+                            a.x = fmaf(wk.x, v.x, a.x); a.y = fmaf(wk.y, v.y, a.y);
+                            a.z = fmaf(wk.z, v.z, a.z); a.w = fmaf(wk.w, v.w, a.w);
+                        }
+                }
+                *reinterpret_cast<float4*>(y4_s + p * 32 + ((cq ^ ((p & 15) >> 1)) << 2)) = a;
+            }
+        }
+    }
+    __syncthreads();
+    float* h_s = y3_s;    // [112][16]
+    {
+        // flow-head parameters (as flow_head_kernel): w1[16][16] | b1 | bn_scale | bn_shift | wf[3][3][16][2]
+        const f32x4v w1v = *reinterpret_cast<const f32x4v*>(head + n * 16 + 4 * g);
+        const float4 b1v = *reinterpret_cast<const float4*>(head + 256 + 4 * g);
+        const float4 bsv = *reinterpret_cast<const float4*>(head + 272 + 4 * g);
+        const float4 btv = *reinterpret_cast<const float4*>(head + 288 + 4 * g);
+        const float4 b4v = *reinterpret_cast<const float4*>(b4 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int grp = wave + 4 * i;
+            if (grp < kTlG4) {   // wave-uniform
+                f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int coff = ((4 * u + g) ^ sw) << 2;
+                    const f32x4v wv = *reinterpret_cast<const f32x4v*>(w4_s + n * 32 + coff);
+                    const f32x4v yv = *reinterpret_cast<const f32x4v*>(y4_s + (16 * grp + n) * 32 + coff);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], yv[t], z4, 0, 0, 0);
+                }
+                // ============ phase C: h = BN(Mish(W1 Mish(z4 + b4) + b1)), zero outside the image ============
+                const float a0 = mishf(z4[0] + b4v.x), a1 = mishf(z4[1] + b4v.y), a2 = mishf(z4[2] + b4v.z),
+                            a3 = mishf(z4[3] + b4v.w);
+                f32x4v d = {0.f, 0.f, 0.f, 0.f};
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[0], a0, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[1], a1, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[2], a2, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[3], a3, d, 0, 0, 0);
+                const int p = 16 * grp + n;
+                const int gy = Y0 - 1 + p / kTlR4, gx = X0 - 1 + p % kTlR4;
+                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < kTlN4 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    h = make_float4(fmaf(mishf(d[0] + b1v.x), bsv.x, btv.x), fmaf(mishf(d[1] + b1v.y), bsv.y, btv.y),
+                                    fmaf(mishf(d[2] + b1v.z), bsv.z, btv.z), fmaf(mishf(d[3] + b1v.w), bsv.w, btv.w));
+                *reinterpret_cast<float4*>(h_s + p * 16 + 4 * g) = h;
+            }
+        }
+    }
+    __syncthreads();
+    // ================= phase D: flow = scale * conv3x3(h), 16 -> 2; wave w = tile rows 2 w, 2 w + 1 ==========
+    {
+        const float* wf = head + 304;
+        const int p = 16 * wave + n, r = p >> 3, c = p & 7;
+        float fx = 0.0f, fy = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 v = *reinterpret_cast<const float4*>(h_s + ((r + ky) * kTlR4 + c + kx) * 16 + 4 * g);
+                const float4 wa = *reinterpret_cast<const float4*>(wf + (ky * 3 + kx) * 32 + 8 * g);
+                const float4 wb = *reinterpret_cast<const float4*>(wf + (ky * 3 + kx) * 32 + 8 * g + 4);
+                fx = fmaf(v.x, wa.x, fx); fy = fmaf(v.x, wa.y, fy);
+                fx = fmaf(v.y, wa.z, fx); fy = fmaf(v.y, wa.w, fy);
+                fx = fmaf(v.z, wb.x, fx); fy = fmaf(v.z, wb.y, fy);
+                fx = fmaf(v.w, wb.z, fx); fy = fmaf(v.w, wb.w, fy);
+            }
+        fx += __shfl_xor(fx, 16); fy += __shfl_xor(fy, 16);
+        fx += __shfl_xor(fx, 32); fy += __shfl_xor(fy, 32);
+        const int gy = Y0 + r, gx = X0 + c;
+        if (g == 0 && gy < H && gx < W) {
+            if (out_nchw) {
+                float* o = out + ((int64_t)(b * 2) * H + gy) * W + gx;
+                o[0] = scale * fx;
+                o[(int64_t)H * W] = scale * fy;
+            } else {
+                float* o = out + ((int64_t)(b * H + gy) * W + gx) * 2;
+                o[0] = scale * fx;
+                o[1] = scale * fy;
+            }
+        }
+    }
+}
+
+int optflow_tail_launch(const void* z2, const void* dw3, const void* pw3, const void* b3, const void* dw4,
+                        const void* pw4, const void* b4, const void* head, void* out, int B, int H, int W,
+                        float scale, int act_in, int out_layout, hipStream_t s) {
+    const int tiles_x = (W + kTlT - 1) / kTlT, tiles_y = (H + kTlT - 1) / kTlT;
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
+    if (nblk > INT32_MAX) {
+        set_error("optflow_tail: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    const dim3 grid((unsigned)nblk);
+    const int nchw = out_layout == QPWC_NCHW;
+#define QPWC_TL(A)                                                                                             \
+    hipLaunchKernelGGL(optflow_tail_kernel<A>, grid, dim3(256), 0, s, (const float*)z2, (const float*)dw3,     \
+                       (const float*)pw3, (const float*)b3, (const float*)dw4, (const float*)pw4,              \
+                       (const float*)b4, (const float*)head, (float*)out, H, W, tiles_x, tiles_y, scale, nchw)
+    if (act_in) QPWC_TL(true); else QPWC_TL(false);
+#undef QPWC_TL
+    return check_launch("optflow_tail_kernel");
+}
+
 int flow_head_param_floats() { return kFhParams; }
 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,

@@ -352,6 +352,10 @@ class OptFlow(_Weighted):
     # first layers of L0 / L1 (593 / 339 channels on 8 / 32 tiles: 19 / 11 dependent 32-channel steps) stay
     # split: 32.5 vs 12.6 and 22.2 vs 17.1.
     fused_sepconv = None
+    # The last two layers + flow head as ONE launch (qpwc_optflow_tail_fwd) up to this many pixels (B*H*W): on the
+    # coarse levels the three launches it replaces are bound by their start-up latency, not by their work
+    # (8 x 8 tiles with recomputed halos: 2.25 x the matrix work of the 64 -> 32 layer, irrelevant there).
+    tail_max_pixels = 16384
 
     @staticmethod
     def _fuse_layer(c_in, n_tiles):
@@ -390,6 +394,9 @@ class OptFlow(_Weighted):
             self._pw_pad84_16 = ops.pad_pointwise(pw84, torch.float16)
             self._dw84 = torch.cat([self._dw[0][:81], self._dw[0].new_zeros((3, 9)), self._dw[0][81:]]).contiguous()
         self._pw_b32 = [b.float().contiguous() for b in self._pw_b]
+        if len(self.filters) == 4:   # dense (F, C) pointwise matrices of the last two layers for qpwc_optflow_tail_fwd
+            self._pw3 = self.p("feat.2.pointwise.weight").reshape(self.filters[2], -1).float().contiguous()
+            self._pw4 = self.p("feat.3.pointwise.weight").reshape(self.filters[3], -1).float().contiguous()
         self._head = pack_flow_head(self.p("conv.weight"), self.p("conv.bias"), self.p("norm.gamma"),
                                     self.p("norm.beta"), self.p("norm.mean"), self.p("norm.var"),
                                     self.BN_EPS, self.p("flow.weight"))
@@ -436,7 +443,14 @@ class OptFlow(_Weighted):
                 return self._fuse_layer(self._dw[i].shape[0], n_tiles)
             return bool(self.fused_sepconv)
 
+        use_tail = (fp32 and self.filters == (128, 64, 32, 16) and B * H * W <= self.tail_max_pixels and
+                    self.fused_sepconv is not False)
         for i in range(n_layers):
+            if use_tail and i == 2:   # z = the second layer's output
+                dw = self._dw
+                return ops.optflow_tail(z, dw[2], self._pw3, self._pw_b32[2], dw[3], self._pw4, self._pw_b32[3],
+                                        self._head, scale, mish_on_load=not z_act,
+                                        out_format=getattr(self, "out_format", CHANNELS_LAST))
             src = sources if i == 0 else [z]
             act_in = i > 0 and not z_act
             first84 = i == 0 and padded_cost
@@ -444,7 +458,7 @@ class OptFlow(_Weighted):
             if fuse(i):  # depthwise + pointwise + bias in one launch, depthwise result stays on chip
                 # store Mish(z) when the next consumer is another fused layer (the flow head and the
                 # split depthwise kernel take pre-activation tensors and activate on load)
-                act_out = fuse(i + 1)
+                act_out = fuse(i + 1) or (use_tail and i == 1)
                 if fp32:
                     pw_i = self._pw_pad84 if first84 else self._pw_pad[i]
                 else:

@@ -369,6 +369,33 @@ def flow_head(z, params, scale, out_format=CHANNELS_LAST):
     return out
 
 
+def optflow_tail(z2, dw3, pw3, b3, dw4, pw4, b4, head_params, scale, mish_on_load=False, out_format=CHANNELS_LAST):
+    """Last two SeparableConv2D (64 -> 32 -> 16) + flow head of OptFlow (non_layers.py:223-231, 238-254,
+    268-273) in one launch (qpwc_optflow_tail_fwd): z2 (B,H,W,64) fp32, the second layer's output (activated
+    unless mish_on_load) -> flow (B,H,W,2) / (B,2,H,W).  For the coarse pyramid levels."""
+    _check_tensor("z2", z2)
+    if z2.dtype != torch.float32 or z2.shape[3] != 64 or not z2.is_contiguous():
+        raise ValueError("z2 must be a dense fp32 (B,H,W,64) tensor")
+    for name, t, shape in (("dw3", dw3, (64, 9)), ("pw3", pw3, (32, 64)), ("b3", b3, (32,)), ("dw4", dw4, (32, 9)),
+                           ("pw4", pw4, (16, 32)), ("b4", b4, (16,))):
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("{} must be a dense fp32 device tensor of shape {}".format(name, shape))
+    L = _hip.lib()
+    if head_params.numel() != L.qpwc_flow_head_param_floats() or head_params.dtype != torch.float32:
+        raise ValueError("head_params must hold {} fp32 values".format(L.qpwc_flow_head_param_floats()))
+    get_axis(out_format)
+    cf = out_format == CHANNELS_FIRST
+    B, H, W, _ = z2.shape
+    out = torch.empty((B, 2, H, W) if cf else (B, H, W, 2), dtype=torch.float32, device=z2.device)
+    with torch.cuda.device(z2.device), _timed("optflow_tail", (B, H, W, 64)):
+        rc = L.qpwc_optflow_tail_fwd(z2.data_ptr(), dw3.data_ptr(), pw3.data_ptr(), b3.data_ptr(), dw4.data_ptr(),
+                                     pw4.data_ptr(), b4.data_ptr(), head_params.data_ptr(), out.data_ptr(), B, H, W,
+                                     float(scale), int(bool(mish_on_load)), _hip.NCHW if cf else _hip.NHWC,
+                                     _stream(z2))
+    _hip.check(rc)
+    return out
+
+
 def bias_mish_(x_nhwc, bias=None):
     """In place x = Mish(x + bias) on a dense channels-last fp32 tensor (..., C), C % 4 == 0 --
     the `activation='Mish'` epilogue of the reference's conv blocks (non_layers.py:196-210,

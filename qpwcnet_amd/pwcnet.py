@@ -102,6 +102,8 @@ class QpwcNet:
         self._side = None
         # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
         self.dec_chunks = (2, 4, 4, 4)
+        # launch order of flow levels (F) and decoder levels (D) in the two-stream forward, see _forward_two_streams
+        self.capture_order = ("F0", "D0", "D1", "D2", "D3", "F1", "F2", "F3", "F4")
         self.input_shape = tuple(input_shape)
         self.device = torch.device(device)
         self.dtype = dtype
@@ -209,7 +211,6 @@ class QpwcNet:
             self._side = torch.cuda.Stream(device=encs[-1].device)
         side = self._side
         side.wait_stream(main)              # encoder outputs are ready
-        decs, ready = [], []
         # One library launch over the 2B stacked frames fills the chip with long-lived workgroups and the small
         # critical-path kernels beside it wait for CUs; two launches of B frames each leave room for them
         # (B=8: 1.343 -> 1.309 ms/step; 4 chunks: no further gain; B=32: the launches are multi-round anyway, -1 %)
@@ -222,27 +223,39 @@ class QpwcNet:
         # created after the fork stays on the encoder's hardware queue and the other branch starts on a second
         # queue some 50-100 us later (kernel trace of the replay: with the decoder captured first, the flow
         # chain -- the critical path -- was the branch that waited).  The decoder has that much slack.
-        flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
-        flos = [flo]
-        with torch.cuda.stream(side):
-            f, i = encs[-1], -2
-            for li, l in enumerate(self.dec):
-                hip_chunks = self.dec_chunks[li] if small else 1
-                f = l.cat_skip(f, encs[i], batch_chunks=chunks, hip_chunks=hip_chunks)
-                i -= 1
-                # allocated on `side`, read by UpFlow on `main`: tell the caching allocator, so that the block
-                # is not handed to a later side-stream allocation while main may still be reading it (the
-                # join at the end orders main after side, not side's NEXT use after main's reads)
-                f.record_stream(main)
-                decs.append(f)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                ready.append(ev)
-        for i, upflow in enumerate(self.upflows):
-            flo_u = self._up(flo)
-            main.wait_event(ready[i])
-            flo = upflow((decs[i][:nb], decs[i][nb:], flo_u))
-            flos.append(flo)
+        # Launch (= capture) order of the two branches: "F<i>" = flow level i on the caller's stream, "D<i>" =
+        # decoder level i on the side stream.  F0 first (see above); then the whole decoder, then F1..F4.
+        # A node that waits on the other queue is released late when much of that queue's work was enqueued
+        # before it: in this order level 1's first launch starts 35-45 us after decoder level 0 has finished
+        # (kernel traces: it follows the START of the last launch of decoder level 1 wherever that is moved).
+        # Interleaving (F0 D0 F1 D1 F2 D2 F3 D3 F4) removes that wait and delays every later decoder level by
+        # more: 1.253 vs 1.197-1.207 ms/step; five orders in between all land within 1 % of this one
+        # (tools/capture_order_ab.py, one call; dropping the wait altogether -- a race -- would be worth 12-18 us).
+        order = self.capture_order
+        ready, decs, flos = {}, {}, []
+        f, k, flo = encs[-1], -2, None
+        for tok in order:
+            i = int(tok[1:])
+            if tok[0] == "D":
+                with torch.cuda.stream(side):
+                    hip_chunks = self.dec_chunks[i] if small else 1
+                    f = self.dec[i].cat_skip(f, encs[k], batch_chunks=chunks, hip_chunks=hip_chunks)
+                    k -= 1
+                    # allocated on `side`, read by UpFlow on `main`: tell the caching allocator, so that the block
+                    # is not handed to a later side-stream allocation while main may still be reading it (the
+                    # join at the end orders main after side, not side's NEXT use after main's reads)
+                    f.record_stream(main)
+                    decs[i] = f
+                    ready[i] = torch.cuda.Event()
+                    ready[i].record(side)
+            elif i == 0:
+                flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
+                flos.append(flo)
+            else:
+                flo_u = self._up(flo)
+                main.wait_event(ready[i - 1])
+                flo = self.upflows[i - 1]((decs[i - 1][:nb], decs[i - 1][nb:], flo_u))
+                flos.append(flo)
         flos.append(self._up(flo, last=True))
         main.wait_stream(side)              # join before anything is freed or returned
         return flos if self.train else flos[-1]

@@ -372,3 +372,41 @@ def test_conv3x3s2_mish_stride2_levels(hw, ci):
     out = ops.conv3x3s2_mish(xp.permute(0, 2, 3, 1).contiguous().to(DEV), ops.conv3x3_taps(w.to(DEV)), b.to(DEV)).cpu()
     assert tuple(out.shape) == (3, H // 2, W // 2, 2 * ci)
     torch.testing.assert_close(out, ref, rtol=0, atol=2e-5 if ci <= 32 else 5e-5)
+
+
+@pytest.mark.parametrize("hw,batch", [((8, 16), 8), ((16, 32), 8), ((32, 64), 2), ((19, 37), 3), ((5, 7), 1), ((64, 128), 1)])
+@pytest.mark.parametrize("act_in", [False, True], ids=["activated-input", "mish-on-load"])
+@pytest.mark.parametrize("out_format", ["channels_last", "channels_first"])
+def test_optflow_tail_one_launch(hw, batch, act_in, out_format):
+    """qpwc_optflow_tail_fwd (SeparableConv2D 64 -> 32 -> 16 + flow head in one launch, 8 x 8 tiles with
+    recomputed halos, every intermediate zero outside the image) against the three launches it replaces and
+    against the torch-CPU restatement of non_layers.py:223-231, 238-254, 268-273; ragged image sizes included."""
+    H, W = hw
+    rng = np.random.default_rng(H * 100 + W + batch)
+    weights = synth.make_weights(42, (256, 512))
+    params = {k: torch.as_tensor(v).to(DEV) for k, v in weights.items()}
+    of = non_layers.OptFlow(params, "upflow.2.flow.", data_format="channels_last")
+    of._prepare_hip()
+    z2 = _rand(rng, batch, H, W, 64)
+    scale = float(H * H + W * W) ** 0.5
+    out = ops.optflow_tail(z2.to(DEV), of._dw[2], of._pw3, of._pw_b32[2], of._dw[3], of._pw4, of._pw_b32[3], of._head,
+                           scale, mish_on_load=act_in, out_format=out_format)
+    if out_format == "channels_first":
+        assert tuple(out.shape) == (batch, 2, H, W)
+        out = out.permute(0, 2, 3, 1)
+    # the launches it replaces
+    z3 = ops.sepconv3x3([z2.to(DEV)], of._dw[2], of._pw_pad[2], of._pw_b32[2], mish_on_load=act_in, mish_on_store=True)
+    z4 = ops.sepconv3x3([z3], of._dw[3], of._pw_pad[3], of._pw_b32[3])
+    three = ops.flow_head(z4, of._head, scale)
+    torch.testing.assert_close(out / scale, three / scale, rtol=0, atol=2e-6)
+    # the oracle's ops
+    def sep(x, i, act):
+        y = torch_ref.depthwise3x3([x], torch.as_tensor(weights["upflow.2.flow.feat.%d.depthwise.weight" % i]), act)
+        pw = torch.as_tensor(weights["upflow.2.flow.feat.%d.pointwise.weight" % i])
+        return torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw, torch.as_tensor(weights["upflow.2.flow.feat.%d.bias" % i])).permute(0, 2, 3, 1)
+    w = lambda k: torch.as_tensor(weights["upflow.2.flow." + k])
+    r3 = torch_ref.mish(sep(z2, 2, act_in))
+    r4 = sep(r3, 3, False)
+    ref = torch_ref.flow_head(r4, w("conv.weight"), w("conv.bias"), w("norm.gamma"), w("norm.beta"), w("norm.mean"),
+                              w("norm.var"), 1e-3, w("flow.weight"), scale)
+    torch.testing.assert_close(out.cpu() / scale, ref / scale, rtol=0, atol=2e-5)

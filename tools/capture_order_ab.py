@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the decoder's launch granularity on the side stream (QpwcNet.dec_chunks: launches per decoder level over
-slices of the 2B stacked frames), whole forward + EPE under hipGraph, B=8 256x512 fp32, one process."""
+"""A/B of the launch (capture) order of flow levels (F) and decoder levels (D) in QpwcNet._forward_two_streams:
+whole forward + EPE under hipGraph, B=8 256x512 fp32, one process."""
 import os
 import sys
 import time
@@ -18,11 +18,21 @@ pairs_np, gt_np = synth.make_frames(B, hw[0], hw[1], seed=1234)
 pairs = torch.from_numpy(pairs_np).to(dev)
 gt_pyr = metrics.multiscale_ground_truth(torch.from_numpy(gt_np).to(dev), [(hw[0] >> s, hw[1] >> s) for s in (5, 4, 3, 2, 1, 0)])
 model = build_flower(True, hw, "channels_last", weights=weights, device=dev)
-cands = [(2, 4, 4, 4), (1, 1, 1, 1), (2, 2, 2, 2), (4, 4, 4, 4), (1, 2, 4, 4), (2, 2, 4, 4), (2, 4, 4, 8), (2, 4, 8, 8)]
+cands = ["F0 D0 D1 D2 D3 F1 F2 F3 F4", "F0 D0 F1 D1 D2 D3 F2 F3 F4", "F0 D0 D1 F1 D2 D3 F2 F3 F4",
+         "F0 D0 D1 F1 D2 F2 D3 F3 F4", "D0 F0 D1 D2 D3 F1 F2 F3 F4", "F0 D0 F1 D1 F2 D2 F3 D3 F4",
+         "F0 D0 D1 D2 F1 D3 F2 F3 F4"]
 graphs = []
+ref = None
 for c in cands:
-    model.dec_chunks = c
-    graphs.append(GraphedForward(model, pairs, epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=2))
+    model.capture_order = tuple(c.split())
+    g = GraphedForward(model, pairs, epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=2)
+    graphs.append(g)
+    g.replay()
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = [f.clone() for f in g.outputs]
+    else:
+        assert all(torch.equal(a, b) for a, b in zip(ref, g.outputs)), c
 res = {c: [] for c in cands}
 for rnd in range(4):
     for c, g in zip(cands, graphs):
