@@ -323,6 +323,7 @@ constexpr int kScNH = kScHH * kScHW;    // 180 halo pixels
 constexpr int kScInPS = 40;             // floats per halo pixel in in_s
 #ifdef QPWC_SC_STAMP
 __device__ long long g_sc_stamps[4 * 64];
+__device__ long long g_sc_census[4096 * 6];   // per workgroup: start, staged0, last-step begin, end, HW_ID, XCC_ID
 #endif
 
 __device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f, 0.f};
@@ -361,7 +362,16 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     long long* stamp_p = g_sc_stamps + (blockIdx.x / 509) * 64;
     int stamp_i = 0;
 #define SC_STAMP() do { if (stamp_on && stamp_i < 62) stamp_p[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+    const bool census_on = lane == 0 && wave == 0 && blockIdx.x < 4096;
+    long long* census_p = g_sc_census + (blockIdx.x < 4096 ? blockIdx.x : 0) * 6;
+    if (census_on) {
+        census_p[0] = __builtin_amdgcn_s_memtime();
+        census_p[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        census_p[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    }
+#define SC_CENSUS(i) do { if (census_on) census_p[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define SC_CENSUS(i) do { } while (0)
 #define SC_STAMP() do { } while (0)
 #endif
 
@@ -593,6 +603,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     commit_in(0);
     __syncthreads();
     SC_STAMP();
+    SC_CENSUS(1);
     if (nsteps > 1) fetch_in(kScKC);
     depthwise(y_s);
     SC_STAMP();
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     commit_w();
     __syncthreads();
     SC_STAMP();
+    SC_CENSUS(2);
     asm volatile("; last step: matrix work, block of 16 outputs by block, each block's bias + Mish + stores behind it");
     // The accumulators of output block ft are final after its 16 matrix instructions: its epilogue (bias,
     // Mish, two 16-byte stores) issues in the matrix pipe's shadow of block ft + 1 instead of after all of
@@ -673,6 +685,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
         SC_STAMP();
         epilogue(NFT - 1);
     }
+    SC_CENSUS(3);
     SC_STAMP();
 }
 
@@ -1630,6 +1643,10 @@ int flow_head_launch(const void* z, const void* params, void* out, int B, int H,
 }  // namespace qpwc
 
 #ifdef QPWC_SC_STAMP
+extern "C" int qpwc_debug_sc_census(long long* out, int n) {
+    if (n > 4096 * 6) n = 4096 * 6;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qpwc::g_sc_census), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
 extern "C" int qpwc_debug_sc_stamps(long long* out, int n) {
     if (n > 4 * 64) n = 4 * 64;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qpwc::g_sc_stamps), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
