@@ -21,10 +21,8 @@ class KernelTimer:
         kt.summary()  # {(op, B, H, W, C): (launches, mean_ms)}
     """
 
-    def __init__(self, capture=None):
+    def __init__(self):
         self.records = []
-        self.capture = capture    # key whose input tensors should be kept (bench: dominant kernel)
-        self.captured = None
 
     def __enter__(self):
         global _TIMER
@@ -48,8 +46,8 @@ class KernelTimer:
 _TIMER = None
 
 
-def kernel_timing(capture=None):
-    return KernelTimer(capture)
+def kernel_timing():
+    return KernelTimer()
 
 
 class _timed:
