@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Replay one hipGraph of the forward (B=8, 256x512 fp32) 40 times with model attributes set from the command line
-(name=value, python literals), for `rocprofv3 --kernel-trace`:  trace_variant.py "dec_chunks=(2,1,4,4)" "capture_order=('F0','D0','F1','D1','D2','D3','F2','F3','F4')""""
+(name=value, python literals), for `rocprofv3 --kernel-trace`:  trace_variant.py "dec_chunks=(2,1,4,4)"
+(or e.g. "capture_order=('F0','D0','F1','D1','D2','D3','F2','F3','F4')")."""
 import ast
 import os
 import sys
