@@ -204,3 +204,85 @@ def test_keras_by_name_round_trip():
     del named["conv2d_3/bias:0"]
     with pytest.raises(KeyError, match="conv2d_3/bias:0"):
         W.from_keras_named(named)
+
+
+# ---- round 2: dispatch rules and bench labels (pure host logic) ---------------------------------------
+def test_fused_front_end_rule_mirrors_the_c_side():
+    """UpFlow fuses WarpV2 + cost volume exactly where cost_volume_mfma_launch takes the fused launch:
+    channels-last fp32 / fp16, C % 32 == 0, >= 256 regions of 8 x 8 pixels, H, W >= 2, search range 4."""
+    class T:   # shape / dtype / device carrier: the rule never touches data
+        def __init__(self, shape, dtype=torch.float32, cuda=True):
+            self.shape, self.dtype, self.is_cuda = shape, dtype, cuda
+        def dim(self):
+            return len(self.shape)
+    ok = non_layers.fused_front_end_applies
+    assert ok(T((8, 128, 256, 32))) and ok(T((8, 64, 128, 64))) and ok(T((8, 32, 64, 128)))   # L4, L3, L2 at B=8
+    assert not ok(T((8, 16, 32, 256)))                  # L1 at B=8: 64 regions
+    assert ok(T((32, 16, 32, 256), torch.float16))      # L1 at B=32: 256 regions
+    assert not ok(T((8, 128, 256, 48)))                 # C % 32
+    assert not ok(T((8, 128, 256, 32)), search_range=3)
+    assert not ok(T((8, 128, 256, 32), cuda=False))
+    assert not ok(T((8, 128, 256, 32), torch.float64))
+
+
+def test_optflow_layer_fusion_rule():
+    f = non_layers.OptFlow._fuse_layer
+    assert f(128, 8) and f(64, 1) and f(32, 1)          # layers 2-4: fused at every level (outputs split over workgroups)
+    assert f(211, 128) and not f(211, 64)               # first layer of L2 at B=8 / fewer tiles
+    assert not f(339, 32) and not f(593, 8)             # wide first layers of L1 / L0 stay depthwise + GEMM
+    assert f(147, 512) and f(115, 2048) and f(593, 256)
+    assert non_layers.OptFlow.tail_max_pixels == 16384  # one-launch tail at L0-L2 for B=8, 256x512
+
+
+def test_bench_labels_follow_the_arguments():
+    import bench
+    assert bench.baseline_config_name(8, (256, 512), "f32", 1) == "BASELINE configs[1]"
+    assert bench.baseline_config_name(8, (256, 512), "f32", 8) == "BASELINE configs[2]"
+    assert bench.baseline_config_name(16, (1024, 2048), "f32", 1) == "BASELINE configs[3]"
+    assert bench.baseline_config_name(32, (256, 512), "f16", 1) == "BASELINE configs[4]"
+    assert bench.baseline_config_name(4, (256, 512), "f32", 1) == "non-BASELINE workload"
+    assert bench.metric_name((1024, 2048), "f32") == "image-pairs/sec at 1024x2048 fp32"
+    assert bench.metric_name((256, 512), "f16") == "image-pairs/sec at 256x512 fp16"
+    # SURVEY 8(d) byte counts per launch
+    assert bench.cost_volume_bytes(8, 128, 256, 32) == 152043520
+    assert bench.warp_bytes(8, 128, 256, 32) == 69206016
+    assert bench.fused_front_bytes(8, 128, 256, 32) == 154140672
+    assert bench.sepconv_flops(8, 128, 256, 115, 128) == 8260157440
+    # the symbol the launcher picks
+    assert bench.cost_volume_symbol(8, 128, 256, 32, "f32") == "cost_volume_mfma_lds_kernel"
+    assert bench.cost_volume_symbol(32, 128, 256, 32, "f16") == "cost_volume_mfma_lds_f16_kernel"
+    assert bench.cost_volume_symbol(8, 16, 32, 256, "f32") == "cost_volume_mfma_kernel"
+    assert bench.cost_volume_symbol(1, 128, 256, 3, "f32") == "cost_volume_tiled_kernel"
+    a = bench.parse_args([])
+    assert (a.gpus, a.batch, a.height, a.width, a.dtype, a.data_format, a.fused) == (1, 8, 256, 512, "f32", "channels_last", None)
+    assert bench.parse_args(["--no-fused"]).fused is False and bench.parse_args(["--fused"]).fused is True
+
+
+def test_model_layout_plan_without_a_device():
+    """A channels_first model on a HIP device runs channels-last inside; on the CPU (no kernels) it keeps the
+    declared layout.  Launch order / decoder granularity attributes exist with their defaults."""
+    from qpwcnet_amd.pwcnet import build_flower
+    m = build_flower(True, (64, 128), "channels_first", weights=synth.make_weights(42, (64, 128)), device="cpu")
+    assert m.data_format == "channels_first" and m._df == "channels_first"
+    assert m.capture_order == ("F0", "D0", "D1", "D2", "D3", "F1", "F2", "F3", "F4") and m.dec_chunks == (2, 4, 4, 4)
+    assert all(u.fused for u in build_flower(True, (64, 128), "channels_last", weights=synth.make_weights(42, (64, 128)),
+                                             device="cpu").upflows)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 64, 128, 6))      # declared channels_first: (B,6,H,W) expected
+
+
+def test_source_hash_and_traffic_file_agree():
+    """profiles/traffic.json is stamped with the sha256 of the hot-path kernel sources; bench.py reports its
+    numbers only while the sources still hash to it."""
+    import json
+    import os
+    from qpwcnet_amd import _hip
+    h = _hip.source_sha256()
+    assert len(h) == 64 and h == _hip.source_sha256()
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    t = json.load(open(path))
+    assert set(("kernel_source_sha256", "tag", "cost_volume_L4_bytes_per_launch", "warp_clamp_L4_bytes_per_launch",
+                "warp_cost_volume_L4_bytes_per_launch")) <= set(t)
+    import bench
+    val, src = bench.load_traffic("cost_volume_L4_bytes_per_launch")
+    assert (val is not None) == (t["kernel_source_sha256"] == h), src
