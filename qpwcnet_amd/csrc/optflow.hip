@@ -689,6 +689,10 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     SC_STAMP();
 }
 
+#ifdef QPWC_SC_WS
+#include "experimental/sepconv_role_split.inc"
+#endif
+
 // ---------------------------------------------------------------------------
 // fp16-storage form of the fused SeparableConv2D (BASELINE configs[4]): either one dense source whose
 // pixels are 16-byte aligned runs of a multiple of 8 channels (OptFlow's layers 2..4, WIDE) or the
@@ -1021,6 +1025,31 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
         set_error("sepconv3x3: unsupported filter count %d (16/32/64/128)", F);
         return QPWC_E_SHAPE;
     }
+#ifdef QPWC_SC_WS
+    {
+        // role-split kernel: every source but the last in whole 16-byte chunks (the last may be a short tail),
+        // no activation on load, byte offsets inside one image below 2^31
+        bool ws = vec && slices == 1 && nblk >= QPWC_SC_WS && (act & 1) == 0;
+        for (int i = 0; i < n_src; ++i)
+            if (((int64_t)H * W * strides[i] + 4) * 4 >= 0x7fffffff) ws = false;
+        if (ws) {
+            const bool oa = (act & 2) != 0;
+#define QPWC_WS_LAUNCH(FF, AO)                                                                           \
+    hipLaunchKernelGGL((sepconv3x3_ws_kernel<FF, AO>), grid, dim3(512), 0, s, d, fdw, fpw, fb, (float*)out, \
+                       B, H, W, C, cpad, tiles_x, tiles_y)
+#define QPWC_WS_F(FF) do { if (oa) QPWC_WS_LAUNCH(FF, true); else QPWC_WS_LAUNCH(FF, false); } while (0)
+            switch (F) {
+                case 128: QPWC_WS_F(128); break;
+                case 64: QPWC_WS_F(64); break;
+                case 32: QPWC_WS_F(32); break;
+                default: QPWC_WS_F(16); break;
+            }
+#undef QPWC_WS_F
+#undef QPWC_WS_LAUNCH
+            return check_launch("sepconv3x3_ws_kernel");
+        }
+    }
+#endif
     switch (F / slices) {   // outputs per workgroup
         case 128: sepconv_dispatch<128>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, slices, s); break;
         case 64: sepconv_dispatch<64>(d, act, vec, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, grid, slices, s); break;
