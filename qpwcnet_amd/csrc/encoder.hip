@@ -57,6 +57,14 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 #ifndef QPWC_ENC_NT
 #define QPWC_ENC_NT 1
 #endif
+#ifdef QPWC_ENC_STAMP
+// diagnostic build only (make ab ABSRC=encoder ABFLAGS=-DQPWC_ENC_STAMP; tools/enc_census.py): per workgroup of
+// the narrow kernel: start, inputs landed, staged (after the barrier), matrix work done, end, HW_ID | XCC_ID << 32
+__device__ long long g_enc_census[4096 * 6];
+#define ENC_CENSUS(i) do { if (census_on) census_p[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ENC_CENSUS(i) do { } while (0)
+#endif
 template <int C, int NT>
 __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ weight,
@@ -103,10 +111,23 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
                 *reinterpret_cast<float4*>(in_s + buf * (kEcNH * C) + hp * C + 4 * ec_slot<C>(q, hp)) = v[it];
         }
     };
+#ifdef QPWC_ENC_STAMP
+    const bool census_on = tid0 == 0 && blockIdx.x < 4096;
+    long long* census_p = g_enc_census + (blockIdx.x < 4096 ? blockIdx.x : 0) * 6;
+    if (census_on)
+        census_p[5] = (long long)(unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                      ((long long)(unsigned)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+#endif
+    ENC_CENSUS(0);
     float4 st[NLD];
     stage_load(tid0, tx0, st);
+#ifdef QPWC_ENC_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ENC_CENSUS(1);
     stage_write(tid0, 0, st);
     __syncthreads();
+    ENC_CENSUS(2);
 
 #pragma unroll 1   // a real loop: unrolled, the compiler hoists the next tiles' weight loads (73 / 102 registers at NT = 2 / 4)
     for (int t = 0; t < NT; ++t) {
@@ -156,6 +177,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
                             for (int m = 0; m < 2; ++m)
                                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][tt], bv[m][tt], acc[m], 0, 0, 0);
                     }
+            if (ft == NFT - 1) ENC_CENSUS(3);
             // ---- bias + Mish: lane = pixel n of tile row 2 wave + m, outputs 16 ft + 4g .. + 3 ----
             const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
 #pragma unroll
@@ -182,6 +204,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
                 *reinterpret_cast<float4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        ENC_CENSUS(4);
         if (more) {
             // buffer (t + 1) & 1 was last read by tile t - 1, whose waves all passed the previous barrier
             stage_write(tid, (t + 1) & (NBUF - 1), st);
@@ -813,3 +836,10 @@ int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, voi
 }
 
 }  // namespace qpwc
+
+#ifdef QPWC_ENC_STAMP
+extern "C" int qpwc_debug_enc_census(long long* out, int n) {
+    if (n > 4096 * 6) n = 4096 * 6;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qpwc::g_enc_census), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
