@@ -60,6 +60,59 @@ def test_argument_validation_needs_no_gpu(hip_lib):
     assert L.qpwc_device_copy(None, q, 64, None) == _hip.E_NULL
 
 
+def test_argument_validation_of_the_next_rows_needs_no_gpu(hip_lib):
+    """The SURVEY 8(f) entry points (OptFlow pieces, encoder convolutions, layout change, multi-level EPE) reject bad
+    arguments before any HIP call, with the same codes as the hot-path pair."""
+    from qpwcnet_amd import _hip
+    buf = (ctypes.c_float * 4096)()
+    base = ctypes.cast(buf, ctypes.c_void_p).value
+    base += (-base) % 16
+    p, q, r = base, base + 4096, base + 8192
+    L = hip_lib
+    NHWC, NCHW, F32 = _hip.NHWC, _hip.NCHW, 0
+    # layout change
+    assert L.qpwc_layout_transpose_fwd(None, q, 1, 2, 2, 4, NCHW, F32, None) == _hip.E_NULL
+    assert L.qpwc_layout_transpose_fwd(p, q, 1, 2, 2, 4, 7, F32, None) == _hip.E_LAYOUT
+    assert L.qpwc_layout_transpose_fwd(p, q, 1, 2, 2, 4, NCHW, 9, None) == _hip.E_DTYPE
+    assert L.qpwc_layout_transpose_fwd(p, q, 1, 0, 2, 4, NCHW, F32, None) == _hip.E_SHAPE
+    assert L.qpwc_layout_transpose_fwd(p, p, 1, 2, 2, 4, NCHW, F32, None) == _hip.E_ALIAS
+    # flow head / upsample / one-launch tail
+    assert L.qpwc_flow_head_fwd(p, q, None, 1, 2, 2, 1.0, F32, NHWC, None) == _hip.E_NULL
+    assert L.qpwc_flow_head_fwd(p, q, r, 1, 2, 2, 1.0, F32, 5, None) == _hip.E_LAYOUT
+    assert L.qpwc_flow_head_fwd(p, q, r, 1, 2, 2, 1.0, 9, NHWC, None) == _hip.E_DTYPE
+    assert L.qpwc_flow_head_fwd(p, q, r, 1, 0, 2, 1.0, F32, NHWC, None) == _hip.E_SHAPE
+    assert L.qpwc_upsample2x_flow_fwd(p, q, 1, 2, 2, 2.0, F32, 5, NHWC, None) == _hip.E_LAYOUT
+    assert L.qpwc_upsample2x_flow_fwd(p, q, 1, 2, 0, 2.0, F32, NHWC, NHWC, None) == _hip.E_SHAPE
+    assert L.qpwc_upsample2x_flow_fwd(p, p, 1, 2, 2, 2.0, F32, NHWC, NHWC, None) == _hip.E_ALIAS
+    tail_ptrs = [p, q, q, q, q, q, q, q, r]
+    assert L.qpwc_optflow_tail_fwd(*(tail_ptrs[:8] + [None]), 1, 2, 2, 1.0, 0, NHWC, None) == _hip.E_NULL
+    assert L.qpwc_optflow_tail_fwd(*tail_ptrs, 1, 2, 2, 1.0, 0, 5, None) == _hip.E_LAYOUT
+    assert L.qpwc_optflow_tail_fwd(*tail_ptrs, 1, 2, 0, 1.0, 0, NHWC, None) == _hip.E_SHAPE
+    assert L.qpwc_optflow_tail_fwd(*([p + 8] + tail_ptrs[1:]), 1, 2, 2, 1.0, 0, NHWC, None) == _hip.E_ALIGN
+    # fused SeparableConv2D
+    vp, ci, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    srcs, chans, strides = (vp * 3)(p, 0, 0), (ci * 3)(32, 0, 0), (i64 * 3)(32, 0, 0)
+    assert L.qpwc_sepconv3x3_fwd(srcs, chans, strides, 4, 0, q, q, q, r, 1, 2, 2, 16, None) == _hip.E_SHAPE   # n_src
+    assert L.qpwc_sepconv3x3_fwd(srcs, chans, strides, 1, 0, q, q, q, r, 1, 2, 2, 24, None) == _hip.E_SHAPE   # F
+    assert L.qpwc_sepconv3x3_fwd(srcs, chans, strides, 1, 7, q, q, q, r, 1, 2, 2, 16, None) == _hip.E_SHAPE   # mish flags
+    assert L.qpwc_sepconv3x3_fwd(srcs, chans, (i64 * 3)(16, 0, 0), 1, 0, q, q, q, r, 1, 2, 2, 16, None) == _hip.E_STRIDE
+    assert L.qpwc_sepconv3x3_fwd(srcs, chans, strides, 1, 0, q, q, q, p, 1, 2, 2, 16, None) == _hip.E_ALIAS
+    assert L.qpwc_sepconv3x3_fwd(srcs, chans, strides, 1, 0, q, q + 4, q, r, 1, 2, 2, 16, None) == _hip.E_ALIGN
+    # encoder convolutions
+    assert L.qpwc_conv3x3_mish_fwd(p, q, q, r, 1, 2, 2, 24, 0, 0, None) == _hip.E_SHAPE
+    assert b"not in {16,32,64,128,256}" in L.qpwc_last_error()
+    assert L.qpwc_conv3x3_mish_fwd(p, q, q, p, 1, 2, 2, 16, 0, 0, None) == _hip.E_ALIAS
+    assert L.qpwc_first_conv_mish_fwd(p, q, q, r, 1, 3, 4, NHWC, None) == _hip.E_SHAPE     # odd height
+    assert L.qpwc_first_conv_mish_fwd(p, q, q, r, 1, 2, 4, 5, None) == _hip.E_LAYOUT
+    # multi-level EPE
+    yt, yp, npix, planes = (vp * 2)(p, q), (vp * 2)(q, 0), (i64 * 2)(4, 4), (i64 * 2)(0, 0)
+    assert L.qpwc_epe_multi_fwd(yt, yp, npix, planes, 2, r, r, None) == _hip.E_NULL           # level 1 prediction missing
+    yp = (vp * 2)(q, q)
+    assert L.qpwc_epe_multi_fwd(yt, yp, npix, planes, 9, r, r, None) == _hip.E_SHAPE
+    assert L.qpwc_epe_multi_fwd(yt, yp, (i64 * 2)(4, 0), planes, 2, r, r, None) == _hip.E_SHAPE
+    assert L.qpwc_epe_multi_fwd(yt, yp, npix, (i64 * 2)(3, 0), 2, r, r, None) == _hip.E_SHAPE   # 4 pixels are not planes of 3
+
+
 def test_check_maps_codes_to_reference_exceptions(hip_lib):
     from qpwcnet_amd import _hip
     with pytest.raises(ValueError):
