@@ -71,6 +71,13 @@ const char* qpwc_build_info(void);
 int qpwc_layout_transpose_fwd(const void* in, void* out, int B, int H, int W, int C, int to_layout, int dtype,
                               void* stream);
 
+/* dst view = src view for two channels-last (B,H,W,C) views with their own strides (elements, order batch / row /
+ * pixel; channels contiguous): the skip half of the decoder's concat([UpConv(x), skip])
+ * (qpwcnet/core/pwcnet.py:186-195), which the reference leaves to tf.concat.  C * element size and every stride
+ * must be whole 16-byte units, both base pointers 16-byte aligned, the two extents disjoint. */
+int qpwc_copy_pixels_fwd(const void* src, void* dst, int B, int H, int W, int C, const int64_t* src_strides,
+                         const int64_t* dst_strides, int dtype, void* stream);
+
 /* Measurement aid ("measure the achievable ceiling on the box with a device copy
  * kernel"): dst[0..bytes) = src[0..bytes), 16 B per lane, bytes % 16 == 0, both 16-byte aligned.
  * Not part of the reference's surface. */

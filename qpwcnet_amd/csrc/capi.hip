@@ -40,6 +40,8 @@ int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* 
                      int n_levels, float* out, float* ws, hipStream_t s);
 int layout_transpose_launch(const void* in, void* out, int B, int H, int W, int C, int to_layout, int dtype,
                             hipStream_t s);
+int copy_pixels_launch(const void* src, void* dst, int B, int H, int W, int64_t row_bytes, int64_t sb, int64_t sy,
+                       int64_t sx, int64_t db, int64_t dy, int64_t dx, hipStream_t s);
 int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
                      int act, const void* weight, void* out, int B, int H, int W, int dtype,
                      hipStream_t s);
@@ -163,6 +165,27 @@ int qpwc_layout_transpose_fwd(const void* in, void* out, int B, int H, int W, in
     if ((uintptr_t)in % es || (uintptr_t)out % es) return fail(QPWC_E_ALIGN, "pointer not aligned to its element size");
     if (overlaps(out, n, in, n)) return fail(QPWC_E_ALIAS, "out overlaps in");
     return layout_transpose_launch(in, out, B, H, W, C, to_layout, dtype, (hipStream_t)stream);
+}
+
+int qpwc_copy_pixels_fwd(const void* src, void* dst, int B, int H, int W, int C, const int64_t* src_strides,
+                         const int64_t* dst_strides, int dtype, void* stream) {
+    if (!src || !dst || !src_strides || !dst_strides) return fail(QPWC_E_NULL, "null pointer argument");
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d C=%d", B, H, W, C);
+    const int64_t es = dtype == QPWC_F32 ? 4 : 2;
+    if ((C * es) % 16) return fail(QPWC_E_SHAPE, "a pixel's %d channels must be whole 16-byte chunks", C);
+    for (int i = 0; i < 3; ++i) {
+        if (src_strides[i] < (i == 2 ? C : 0) || dst_strides[i] < (i == 2 ? C : 0))
+            return fail(QPWC_E_STRIDE, "stride %d smaller than what it spans", i);
+        if ((src_strides[i] * es) % 16 || (dst_strides[i] * es) % 16)
+            return fail(QPWC_E_STRIDE, "strides must be multiples of 16 bytes");
+    }
+    if (((uintptr_t)src | (uintptr_t)dst) % 16) return fail(QPWC_E_ALIGN, "pointers must be 16-byte aligned");
+    const size_t sext = (size_t)(((B - 1) * src_strides[0] + (H - 1) * src_strides[1] + (W - 1) * src_strides[2] + C) * es);
+    const size_t dext = (size_t)(((B - 1) * dst_strides[0] + (H - 1) * dst_strides[1] + (W - 1) * dst_strides[2] + C) * es);
+    if (overlaps(dst, dext, src, sext)) return fail(QPWC_E_ALIAS, "dst overlaps src");
+    return copy_pixels_launch(src, dst, B, H, W, C * es, src_strides[0] * es, src_strides[1] * es, src_strides[2] * es,
+                              dst_strides[0] * es, dst_strides[1] * es, dst_strides[2] * es, (hipStream_t)stream);
 }
 
 int qpwc_device_copy(const void* src, void* dst, int64_t bytes, void* stream) {

@@ -77,4 +77,55 @@ int layout_transpose_launch(const void* in, void* out, int B, int H, int W, int 
     return check_launch("layout_transpose_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// Copy of a channels-last (B,H,W,C) view into another one, both with their own batch / row / pixel strides and
+// contiguous channels: the skip half of the decoder's concat([UpConv(x), skip]) (qpwcnet/core/pwcnet.py:186-195) --
+// source = the un-padded view of the encoder's zero-bordered output, destination = channels F.. of the concat
+// buffer.  One 16-byte chunk per thread and trip, four trips in flight; a pixel's chunks sit in neighbouring lanes.
+__global__ __launch_bounds__(256) void copy_pixels_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                         int H, int W, int nq, int64_t total, int64_t sb,
+                                                         int64_t sy, int64_t sx, int64_t db, int64_t dy,
+                                                         int64_t dx) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    auto offs = [&](int64_t i, int64_t& so, int64_t& d_o) {
+        const int q = (int)(i % nq);
+        int64_t p = i / nq;
+        const int x = (int)(p % W);
+        p /= W;
+        const int y = (int)(p % H);
+        const int64_t b = p / H;
+        so = b * sb + y * sy + x * sx + 16 * q;
+        d_o = b * db + y * dy + x * dx + 16 * q;
+    };
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * nthr < total; i += 4 * nthr) {
+        int64_t so[4], d_o[4];
+        f4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) offs(i + k * nthr, so[k], d_o[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f4*>(src + so[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f4*>(dst + d_o[k]) = v[k];
+    }
+    for (; i < total; i += nthr) {
+        int64_t so, d_o;
+        offs(i, so, d_o);
+        *reinterpret_cast<f4*>(dst + d_o) = *reinterpret_cast<const f4*>(src + so);
+    }
+}
+
+// strides in BYTES here (the C-ABI takes elements)
+int copy_pixels_launch(const void* src, void* dst, int B, int H, int W, int64_t row_bytes, int64_t sb, int64_t sy,
+                       int64_t sx, int64_t db, int64_t dy, int64_t dx, hipStream_t s) {
+    const int nq = (int)(row_bytes / 16);
+    const int64_t total = (int64_t)B * H * W * nq;
+    const int64_t want = (total + 4 * 256 - 1) / (4 * 256);
+    const dim3 grid((unsigned)(want < 1 ? 1 : (want > 16384 ? 16384 : want)));
+    hipLaunchKernelGGL(copy_pixels_kernel, grid, dim3(256), 0, s, (const char*)src, (char*)dst, H, W, nq, total, sb, sy,
+                       sx, db, dy, dx);
+    return check_launch("copy_pixels_kernel");
+}
+
 }  // namespace qpwc

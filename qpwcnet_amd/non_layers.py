@@ -194,6 +194,9 @@ class UpConv(_Weighted):
         return self._fmt(_bias_mish(y, self.p("conv_up.bias"), self.p32("conv_up.bias"), self.data_format))
 
     hip_upconv = True
+    # the skip half of the concat by qpwc_copy_pixels_fwd instead of tensor.copy_: same step time on the side stream
+    # (tools/skipcopy_ab.py: 1.198 vs 1.195 ms/step), so the library copy stays the default
+    skip_copy_hip = False
 
     def _hip_upconv_ok(self, x, skip):
         w = self.p("conv_up.weight")
@@ -219,7 +222,11 @@ class UpConv(_Weighted):
                     ops.upconv4x4s2_mish_into(x[i * nb:(i + 1) * nb], t, self.p32("conv_up.bias"), buf[i * nb:(i + 1) * nb])
             else:
                 ops.upconv4x4s2_mish_into(x, t, self.p32("conv_up.bias"), buf)
-            buf[..., t.shape[1]:] = skip
+            half = buf[..., t.shape[1]:]
+            if self.skip_copy_hip and ops.copy_pixels_ok(skip, half):
+                ops.copy_pixels(skip, half)     # own strided copy instead of the library's elementwise kernel
+            else:
+                half.copy_(skip)
             return buf
         # (library path) batch_chunks > 1: the transposed convolution as that many launches over slices of the batch (what
         # pwcnet._forward_two_streams asks for when this runs on the side stream beside the coarse flow levels)

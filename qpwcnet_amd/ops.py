@@ -4,6 +4,8 @@ Each function validates shapes/dtypes/devices the way the reference's graph
 construction would, then calls the C ABI (``include/qpwc.h``) on the caller's
 current HIP stream.  There is no CPU path: a non-GPU tensor is an error.
 """
+import ctypes
+
 import torch
 
 from . import _hip
@@ -133,6 +135,36 @@ def layout_transpose(x, to_format):
                                                    _DTYPES[x.dtype], _stream(x))
     _hip.check(rc)
     return out
+
+
+def copy_pixels_ok(src, dst):
+    """Whether copy_pixels() can take this pair of (B,H,W,C) views: same shape and dtype, channels contiguous, whole
+    16-byte units everywhere (qpwc_copy_pixels_fwd's contract)."""
+    if src.dim() != 4 or src.shape != dst.shape or src.dtype != dst.dtype or src.dtype not in _DTYPES or \
+            not (src.is_cuda and dst.is_cuda) or src.stride(3) != 1 or dst.stride(3) != 1:
+        return False
+    es = src.element_size()
+    if (src.shape[3] * es) % 16 or src.data_ptr() % 16 or dst.data_ptr() % 16:
+        return False
+    return all((t.stride(i) * es) % 16 == 0 and t.stride(i) >= 0 for t in (src, dst) for i in range(3))
+
+
+def copy_pixels(src, dst):
+    """dst[...] = src for two channels-last (B,H,W,C) views with their own batch / row / pixel strides
+    (qpwc_copy_pixels_fwd): the skip half of the decoder's concat([UpConv(x), skip]) (pwcnet.py:186-195)."""
+    _check_tensor("src", src)
+    _check_tensor("dst", dst)
+    if not copy_pixels_ok(src, dst):
+        raise ValueError("copy_pixels needs two (B,H,W,C) views of one shape and dtype with contiguous channels in "
+                         "whole 16-byte units")
+    B, H, W, C = src.shape
+    ss = (ctypes.c_int64 * 3)(src.stride(0), src.stride(1), src.stride(2))
+    ds = (ctypes.c_int64 * 3)(dst.stride(0), dst.stride(1), dst.stride(2))
+    with torch.cuda.device(src.device), _timed("copy_pixels", (B, H, W, C)):
+        rc = _hip.lib().qpwc_copy_pixels_fwd(src.data_ptr(), dst.data_ptr(), B, H, W, C, ss, ds, _DTYPES[src.dtype],
+                                             _stream(src))
+    _hip.check(rc)
+    return dst
 
 
 def _nchw_fast_path(C, search_range=4):

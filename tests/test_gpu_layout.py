@@ -116,3 +116,45 @@ def test_full_network_channels_first_equals_channels_last(hw, batch):
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         m_f(x_l)            # wrong layout for the declared format
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 16), (3, 8, 16, 32), (1, 33, 19, 8), (16, 16, 32, 64)])
+def test_copy_pixels_between_strided_views(shape, dtype):
+    """qpwc_copy_pixels_fwd: the skip half of the decoder's concat -- source = the un-padded view of a zero-bordered
+    tensor, destination = the upper channels of a wider buffer; bit-exact, nothing outside the view touched."""
+    B, H, W, C = shape
+    if (C * torch.empty((), dtype=dtype).element_size()) % 16:
+        pytest.skip("needs whole 16-byte chunks")
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(5)
+    padded = torch.randn(B, H + 1, W + 1, C, device=dev, generator=g).to(dtype)
+    src = padded[:, :H, :W, :]
+    extra = 16
+    buf = torch.full((B, H, W, extra + C), 7.0, device=dev, dtype=dtype)
+    dst = buf[..., extra:]
+    assert ops.copy_pixels_ok(src, dst)
+    ops.copy_pixels(src, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+    assert torch.equal(buf[..., :extra], torch.full((B, H, W, extra), 7.0, device=dev, dtype=dtype))
+    # what the C side refuses: overlapping views, misaligned channel counts
+    with pytest.raises(ValueError):
+        ops.copy_pixels(padded[:, :H, :W, :], padded[:, 1:, 1:, :])
+    assert not ops.copy_pixels_ok(src[..., 1:], dst[..., 1:])
+
+
+def test_decoder_concat_uses_the_copy_kernel_and_matches_tensor_copy():
+    hw, B = (64, 128), 2
+    weights = synth.make_weights(3, hw)
+    pairs_np, _ = synth.make_frames(B, hw[0], hw[1], seed=9)
+    pairs = torch.from_numpy(pairs_np).to("cuda:0")
+    model = build_flower(True, hw, "channels_last", weights=weights, device="cuda:0")
+    with torch.no_grad():
+        a = model(pairs)
+        for d in model.dec:
+            d.skip_copy_hip = True
+        b = model(pairs)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
