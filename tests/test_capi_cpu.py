@@ -76,6 +76,14 @@ def test_argument_validation_of_the_next_rows_needs_no_gpu(hip_lib):
     assert L.qpwc_layout_transpose_fwd(p, q, 1, 2, 2, 4, NCHW, 9, None) == _hip.E_DTYPE
     assert L.qpwc_layout_transpose_fwd(p, q, 1, 0, 2, 4, NCHW, F32, None) == _hip.E_SHAPE
     assert L.qpwc_layout_transpose_fwd(p, p, 1, 2, 2, 4, NCHW, F32, None) == _hip.E_ALIAS
+    # strided view copy (decoder concat)
+    st = (ctypes.c_int64 * 3)(64, 16, 4)
+    assert L.qpwc_copy_pixels_fwd(p, q, 1, 2, 2, 4, st, None, F32, None) == _hip.E_NULL
+    assert L.qpwc_copy_pixels_fwd(p, q, 1, 2, 2, 3, st, st, F32, None) == _hip.E_SHAPE      # 12-byte pixels
+    assert L.qpwc_copy_pixels_fwd(p, q, 1, 2, 2, 4, (ctypes.c_int64 * 3)(64, 16, 2), st, F32, None) == _hip.E_STRIDE
+    assert L.qpwc_copy_pixels_fwd(p, q, 1, 2, 2, 4, (ctypes.c_int64 * 3)(64, 18, 4), st, F32, None) == _hip.E_STRIDE
+    assert L.qpwc_copy_pixels_fwd(p, p + 16, 1, 2, 2, 4, st, st, F32, None) == _hip.E_ALIAS
+    assert L.qpwc_copy_pixels_fwd(p + 4, q, 1, 2, 2, 4, st, st, F32, None) == _hip.E_ALIGN
     # flow head / upsample / one-launch tail
     assert L.qpwc_flow_head_fwd(p, q, None, 1, 2, 2, 1.0, F32, NHWC, None) == _hip.E_NULL
     assert L.qpwc_flow_head_fwd(p, q, r, 1, 2, 2, 1.0, F32, 5, None) == _hip.E_LAYOUT
