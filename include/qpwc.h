@@ -272,6 +272,12 @@ int qpwc_occlusion_fwd(const void* flow, void* out, int B, int H, int W, int lay
 int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,
                           int W, int C, int pad_h, int pad_w, void* stream);
 
+/* The same layer for fp16 storage (BASELINE configs[4]; mixed_float16 in the reference's train.py): x, weight
+ * ((9, C, C) = [ky*3+kx][out][in]) and out fp16, bias fp32; fp32 accumulation on the fp16 matrix instructions,
+ * bias + Mish in fp32, one rounding to fp16 at the store.  Same shapes, padding and alignment rules. */
+int qpwc_conv3x3_mish_f16_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,
+                              int W, int C, int pad_h, int pad_w, void* stream);
+
 /* First encoder layer on the raw input pair: Split(2) (pwcnet.py:229) + both frames stacked on the
  * batch axis (shared encoder weights, pwcnet.py:145-162) + enc.0.conv_a = Conv2D(3 -> 16, 3x3, stride 2,
  * padding='same' [TensorFlow: 0 before, 1 after for even H, W], activation='Mish')

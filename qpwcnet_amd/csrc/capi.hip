@@ -75,6 +75,8 @@ int conv3x3s2_mish_any_launch(const void* x, const void* weight, const void* bia
                               int CI, hipStream_t s);
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s);
+int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                        int C, int pad_h, int pad_w, hipStream_t s);
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                            int layout, hipStream_t s);
 int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
@@ -533,6 +535,20 @@ int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, v
     if (overlaps(out, (size_t)B * (H + pad_h) * (W + pad_w) * C * 4, x, (size_t)B * H * W * C * 4))
         return fail(QPWC_E_ALIAS, "out overlaps x");
     return conv3x3_mish_launch(x, weight, bias, out, B, H, W, C, pad_h, pad_w, (hipStream_t)stream);
+}
+
+int qpwc_conv3x3_mish_f16_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,
+                              int W, int C, int pad_h, int pad_w, void* stream) {
+    if (!x || !weight || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (C != 16 && C != 32 && C != 64 && C != 128 && C != 256)
+        return fail(QPWC_E_SHAPE, "C=%d not in {16,32,64,128,256}", C);
+    if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || pad_h > 8 || pad_w > 8)
+        return fail(QPWC_E_SHAPE, "bad shape B=%d H=%d W=%d pad=%d,%d", B, H, W, pad_h, pad_w);
+    if ((uintptr_t)x % 16 || (uintptr_t)weight % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
+        return fail(QPWC_E_ALIGN, "x, weight, bias, out must be 16-byte aligned");
+    if (overlaps(out, (size_t)B * (H + pad_h) * (W + pad_w) * C * 2, x, (size_t)B * H * W * C * 2))
+        return fail(QPWC_E_ALIAS, "out overlaps x");
+    return conv3x3_mish_f16_launch(x, weight, bias, out, B, H, W, C, pad_h, pad_w, (hipStream_t)stream);
 }
 
 int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,

@@ -354,6 +354,213 @@ static int conv3x3_mish_wide_launch(const void* x, const void* weight, const voi
 }
 
 // ---------------------------------------------------------------------------
+// fp16-storage twin of the two kernels above (BASELINE configs[4]; the reference's mixed_float16 policy, train.py):
+// x, weight ([9 taps][C out][C in]) and out fp16, bias fp32; products on v_mfma_f32_16x16x32_f16 with fp32
+// accumulation, bias + Mish in fp32, ONE rounding to fp16 at the store (the library path it replaces rounds the
+// convolution output and the activation).  One matrix instruction per tap and 32-channel block where fp32 needs
+// eight, so the layer is bound by its activations' bytes; the structure is kept simple: 8 x 16 (TH x 16) pixel tile,
+// the whole halo tile of all input channels in LDS (pixels of CP = max(C, 32) halves, 16-byte chunk q of halo pixel p
+// at slot f16_slot(q, p)), a workgroup = 4 waves = TH / 4 tile rows each x min(C, 64) outputs (grid = tiles x C / 64),
+// the weights streamed from L1 / L2 (16 bytes per lane, tap and output block).  C = 16: the upper half of every
+// 32-channel pixel is zero in LDS and the weight lanes of k >= 16 are zero.
+typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+
+template <int CP>
+__device__ __forceinline__ int f16_slot(int q, int hp) {
+    // pixels of 64 / 128 / 256 / 512 bytes: 16 consecutive pixels x one chunk must spread over the 16 sixteen-byte
+    // slots of the 64 banks
+    return CP == 32 ? (q ^ ((0 - (hp >> 2)) & 3)) : (CP == 64 ? (q ^ ((hp >> 1) & 7)) : (q ^ (hp & 15)));
+}
+
+template <int C, int TH>
+__global__ __launch_bounds__(256) void conv3x3_mish_f16_kernel(const __half* __restrict__ x,
+                                                              const __half* __restrict__ weight,
+                                                              const float* __restrict__ bias,
+                                                              __half* __restrict__ out, int H, int W, int pad_h,
+                                                              int pad_w, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int CP = C < 32 ? 32 : C;            // halves per pixel in LDS
+    constexpr int NQ = CP / 8, NQG = C / 8;        // 16-byte chunks per pixel: LDS / global
+    constexpr int HH = TH + 2, NH = HH * kEcHW;
+    constexpr int NKB = CP / 32;
+    constexpr int FW = C < 64 ? C : 64, NFT = FW / 16, NSL = C / FW;   // outputs per workgroup, blocks, slices
+    constexpr int RW = TH / 4;                     // tile rows per wave
+    constexpr int NST = (NH * NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __half in_s[NH * CP];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int slice = blockIdx.x / n_tiles;
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * TH;
+    const int f0 = FW * slice;
+    const __half* xb = x + (int64_t)b * H * W * C;
+    {
+        uint4 st[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            st[it] = (idx < NH * NQ && q < NQG && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                         ? *reinterpret_cast<const uint4*>(xb + ((int64_t)gy * W + gx) * C + 8 * q)
+                         : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            if (idx < NH * NQ) *reinterpret_cast<uint4*>(in_s + hp * CP + 8 * f16_slot<CP>(q, hp)) = st[it];
+        }
+    }
+    const int Ho = H + pad_h, Wo = W + pad_w;
+    __half* ob = out + (int64_t)b * Ho * Wo * C;
+    if (C >= 64) {
+        // wide levels: a wave owns ONE block of 16 outputs for all TH tile rows and keeps that block's weights for 32
+        // input channels in registers (9 taps x 16 bytes, the next block's requested before this block's matrix work)
+        // -- no weight is fetched twice by a workgroup, every B operand read feeds one matrix instruction
+        const int fo = f0 + 16 * wave;
+        f32x4e acw[TH];
+#pragma unroll
+        for (int r = 0; r < TH; ++r) acw[r] = f32x4e{0.f, 0.f, 0.f, 0.f};
+        f16x8e wv[9], wn[9];
+        auto load_w = [&](f16x8e (&w)[9], int kb) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                w[tap] = *reinterpret_cast<const f16x8e*>(weight + ((int64_t)tap * C + fo + n) * C + 32 * kb + 8 * g);
+        };
+        load_w(wv, 0);
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb + 1 < NKB) load_w(wn, kb + 1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+                for (int r = 0; r < TH; ++r) {
+                    const int hp = (r + ky) * kEcHW + n + kx;
+                    const f16x8e bv = *reinterpret_cast<const f16x8e*>(in_s + hp * CP + 8 * f16_slot<CP>(4 * kb + g, hp));
+                    acw[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[tap], bv, acw[r], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wv[tap] = wn[tap];
+        }
+        const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+            const int gy = Y0 + r, gx = X0 + n;
+            if (gy < H && gx < W) {
+                f16x4e o;
+                o[0] = (_Float16)enc_mishf(acw[r][0] + bq.x);
+                o[1] = (_Float16)enc_mishf(acw[r][1] + bq.y);
+                o[2] = (_Float16)enc_mishf(acw[r][2] + bq.z);
+                o[3] = (_Float16)enc_mishf(acw[r][3] + bq.w);
+                *reinterpret_cast<f16x4e*>(ob + ((int64_t)gy * Wo + gx) * C + fo + 4 * g) = o;
+            }
+        }
+    } else {
+    f32x4e acc[RW][NFT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) acc[r][ft] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const bool kvalid = 8 * g < C;   // C = 16: lanes of k >= 16 carry zeros
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            f16x8e wv[NFT];
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                wv[ft] = f16x8e{0, 0, 0, 0, 0, 0, 0, 0};
+                if (kvalid)
+                    wv[ft] = *reinterpret_cast<const f16x8e*>(weight + ((int64_t)tap * C + f0 + 16 * ft + n) * C + 32 * kb + 8 * g);
+            }
+            f16x8e bv[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int hp = (RW * wave + r + ky) * kEcHW + n + kx;
+                bv[r] = *reinterpret_cast<const f16x8e*>(in_s + hp * CP + 8 * f16_slot<CP>(4 * kb + g, hp));
+            }
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    acc[r][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ft], bv[r], acc[r][ft], 0, 0, 0);
+        }
+    }
+    // ---- bias + Mish, one rounding to fp16: lane = pixel n of tile row RW wave + r, outputs f0 + 16 ft + 4g .. + 3 ----
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        const float4 bq = *reinterpret_cast<const float4*>(bias + f0 + 16 * ft + 4 * g);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int gy = Y0 + RW * wave + r, gx = X0 + n;
+            if (gy < H && gx < W) {
+                f16x4e o;
+                o[0] = (_Float16)enc_mishf(acc[r][ft][0] + bq.x);
+                o[1] = (_Float16)enc_mishf(acc[r][ft][1] + bq.y);
+                o[2] = (_Float16)enc_mishf(acc[r][ft][2] + bq.z);
+                o[3] = (_Float16)enc_mishf(acc[r][ft][3] + bq.w);
+                *reinterpret_cast<f16x4e*>(ob + ((int64_t)gy * Wo + gx) * C + f0 + 16 * ft + 4 * g) = o;
+            }
+        }
+    }
+    }
+    // ---- zero border of the padded output, this slice's FW channels (FW / 8 sixteen-byte chunks per pixel) ----
+    constexpr int NQF = FW / 8;
+    if (pad_w > 0 && X0 + kEcTW >= W) {
+        for (int i = tid; i < TH * pad_w * NQF; i += 256) {
+            const int q = i % NQF, r = i / NQF, col = r % pad_w, row = r / pad_w;
+            const int gy = Y0 + row;
+            if (gy < H) *reinterpret_cast<uint4*>(ob + ((int64_t)gy * Wo + W + col) * C + f0 + 8 * q) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    if (pad_h > 0 && Y0 + TH >= H) {
+        const int x_end = (X0 + kEcTW >= W) ? Wo : X0 + kEcTW;   // the corner belongs to the last tile
+        for (int i = tid; i < pad_h * (x_end - X0) * NQF; i += 256) {
+            const int q = i % NQF, r = i / NQF, col = r % (x_end - X0), row = r / (x_end - X0);
+            *reinterpret_cast<uint4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + f0 + 8 * q) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    (void)NSL;
+}
+
+template <int C, int TH>
+static int conv3x3_mish_f16_launch_t(const void* x, const void* weight, const void* bias, void* out, int B, int H,
+                                     int W, int pad_h, int pad_w, hipStream_t s) {
+    constexpr int NSL = C < 64 ? 1 : C / 64;
+    const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles * NSL > INT32_MAX) {
+        set_error("conv3x3_mish_f16: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((conv3x3_mish_f16_kernel<C, TH>), dim3((unsigned)(n_tiles * NSL)), dim3(256), 0, s,
+                       (const __half*)x, (const __half*)weight, (const float*)bias, (__half*)out, H, W, pad_h, pad_w,
+                       tiles_x, tiles_y, (int)n_tiles);
+    return check_launch("conv3x3_mish_f16_kernel");
+}
+
+int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                            int C, int pad_h, int pad_w, hipStream_t s) {
+    switch (C) {
+        case 16: return conv3x3_mish_f16_launch_t<16, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+        case 32: return conv3x3_mish_f16_launch_t<32, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+        case 64: return conv3x3_mish_f16_launch_t<64, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+        case 128: return conv3x3_mish_f16_launch_t<128, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+        case 256: return conv3x3_mish_f16_launch_t<256, 4>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+        default: set_error("conv3x3_mish_f16: C=%d not in {16,32,64,128,256}", C); return QPWC_E_SHAPE;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // UpConv of the decoder (non_layers.py:196-210): Conv2DTranspose(F, 4x4, stride 2, 'same') + bias + Mish,
 // written straight into channels [0, F) of the concat([up, skip]) buffer (pwcnet.py:186-195).
 // out[2y+py, 2x+px] only sees the 2 x 2 taps of the 4 x 4 kernel that match its parity:

@@ -285,7 +285,7 @@ class DownConv(_Weighted):
         pad_ok = want_padded and _same_pad(h, 3, 2) == (0, 1) and _same_pad(w, 3, 2) == (0, 1)
         if self._hip_conv_ok(y):
             # narrow levels: conv + bias + Mish (+ the next level's 'SAME' padding) in one HIP launch each
-            taps = self._taps()
+            taps = self._taps(y.dtype)
             y1 = ops.conv3x3_mish(y.permute(0, 2, 3, 1), taps[0], self.p32("conv_aa.bias"))
             pad = 1 if pad_ok else 0
             y2 = ops.conv3x3_mish(y1, taps[1], self.p32("conv_b.bias"), pad, pad)
@@ -314,8 +314,8 @@ class DownConv(_Weighted):
                 padded_in.shape[1] % 2 == 1 and padded_in.shape[2] % 2 == 1)
 
     def _hip_conv_ok(self, y_nchw):
-        return (self.hip_conv and y_nchw.dtype == torch.float32 and y_nchw.shape[1] in (16, 32, 64, 128, 256) and
-                _hip_act_ok(y_nchw, self.data_format))
+        return (self.hip_conv and y_nchw.dtype in (torch.float32, torch.float16) and
+                y_nchw.shape[1] in (16, 32, 64, 128, 256) and _hip_act_ok(y_nchw, self.data_format))
 
     def first_layer(self, pairs, pairs_format=None):
         """enc.0.conv_a on the raw (B,H,W,6) pair -- (B,6,H,W) for pairs_format 'channels_first' --: split,
@@ -335,12 +335,12 @@ class DownConv(_Weighted):
             t = self.params[key] = ops.first_conv_taps(w)
         return ops.first_conv_mish(pairs.contiguous(), t, self.p32("conv_a.bias"), pf)
 
-    def _taps(self):
-        key = self.prefix + "#taps"
+    def _taps(self, dtype=torch.float32):
+        key = self.prefix + ("#taps" if dtype == torch.float32 else "#taps_f16")
         t = self.params.get(key)
         if t is None:
-            t = self.params[key] = (ops.conv3x3_taps(self.p("conv_aa.weight")),
-                                    ops.conv3x3_taps(self.p("conv_b.weight")))
+            t = self.params[key] = (ops.conv3x3_taps(self.p("conv_aa.weight"), dtype),
+                                    ops.conv3x3_taps(self.p("conv_b.weight"), dtype))
         return t
 
 

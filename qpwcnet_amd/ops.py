@@ -627,10 +627,10 @@ def _sepconv3x3_f16(keep, c_ptrs, c_ch, c_st, w, pw_padded, bias, flags, B, H, W
     return out
 
 
-def conv3x3_taps(weight):
-    """torch Conv2d weight (C_out, C_in, 3, 3) -> the (9, C_out, C_in) fp32 tap-major layout of
-    qpwc_conv3x3_mish_fwd."""
-    return weight.float().permute(2, 3, 0, 1).reshape(9, weight.shape[0], weight.shape[1]).contiguous()
+def conv3x3_taps(weight, dtype=torch.float32):
+    """torch Conv2d weight (C_out, C_in, 3, 3) -> the (9, C_out, C_in) tap-major layout of
+    qpwc_conv3x3_mish_fwd (fp32) / qpwc_conv3x3_mish_f16_fwd (dtype=torch.float16)."""
+    return weight.to(dtype).permute(2, 3, 0, 1).reshape(9, weight.shape[0], weight.shape[1]).contiguous()
 
 
 def conv3x3_mish(x_nhwc, taps, bias, pad_h=0, pad_w=0):
@@ -638,17 +638,18 @@ def conv3x3_mish(x_nhwc, taps, bias, pad_h=0, pad_w=0):
     conv_aa / conv_b, non_layers.py:410-449), written into a (B, H+pad_h, W+pad_w, C) tensor whose
     border is zero (the 'SAME' padding of a following stride-2 conv).  taps from conv3x3_taps()."""
     _check_tensor("x", x_nhwc)
-    if x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous():
-        raise ValueError("conv3x3_mish needs a dense fp32 channels-last tensor")
+    if x_nhwc.dtype not in (torch.float32, torch.float16) or not x_nhwc.is_contiguous():
+        raise ValueError("conv3x3_mish needs a dense fp32 / fp16 channels-last tensor")
     B, H, W, C = x_nhwc.shape
-    if tuple(taps.shape) != (9, C, C) or taps.dtype != torch.float32 or not taps.is_cuda or \
+    if tuple(taps.shape) != (9, C, C) or taps.dtype != x_nhwc.dtype or not taps.is_cuda or \
             not taps.is_contiguous() or bias.numel() != C or bias.dtype != torch.float32 or not bias.is_cuda:
-        raise ValueError("taps must be a dense fp32 (9,{0},{0}) device tensor, bias fp32 ({0})".format(C))
-    out = torch.empty((B, H + pad_h, W + pad_w, C), dtype=torch.float32, device=x_nhwc.device)
-    with torch.cuda.device(out.device), _timed("conv3x3_mish", (B, H, W, C)):
-        rc = _hip.lib().qpwc_conv3x3_mish_fwd(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(),
-                                              out.data_ptr(), B, H, W, C, int(pad_h), int(pad_w),
-                                              _stream(out))
+        raise ValueError("taps must be a dense (9,{0},{0}) device tensor of the input's dtype, bias fp32 ({0})".format(C))
+    out = torch.empty((B, H + pad_h, W + pad_w, C), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    fn = _hip.lib().qpwc_conv3x3_mish_fwd if x_nhwc.dtype == torch.float32 else _hip.lib().qpwc_conv3x3_mish_f16_fwd
+    with torch.cuda.device(out.device), _timed("conv3x3_mish" if x_nhwc.dtype == torch.float32 else "conv3x3_mish_f16",
+                                               (B, H, W, C)):
+        rc = fn(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C, int(pad_h), int(pad_w),
+                _stream(out))
     _hip.check(rc)
     return out
 

@@ -341,6 +341,27 @@ def test_conv3x3_mish_encoder_kernel(C, hw, pad):
         assert float(out[:, H:].abs().max()) == 0.0 and float(out[:, :, W:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("pad", [0, 1])
+@pytest.mark.parametrize("hw", [(8, 16), (21, 37), (64, 128)])
+@pytest.mark.parametrize("C", [16, 32, 64, 128, 256])
+def test_conv3x3_mish_encoder_kernel_fp16_storage(C, hw, pad):
+    """The fp16-storage twin (qpwc_conv3x3_mish_f16_fwd, BASELINE configs[4]): fp16 operands, fp32 accumulation,
+    ONE rounding at the store -- against fp32 torch on the same fp16-rounded operands; the bound is the rounding
+    of the stored value (2^-11 relative) plus accumulation-order noise."""
+    rng = np.random.default_rng(C + hw[0] + pad + 7)
+    H, W = hw
+    x = _rand(rng, 2, H, W, C).half()
+    w = (_rand(rng, C, C, 3, 3) / np.sqrt(9 * C)).half()
+    b = _rand(rng, C)
+    ref = torch_ref.mish(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, padding=1)).permute(0, 2, 3, 1)
+    out = ops.conv3x3_mish(x.to(DEV), ops.conv3x3_taps(w.to(DEV), torch.float16), b.to(DEV), pad, pad).cpu()
+    assert out.dtype == torch.float16 and tuple(out.shape) == (2, H + pad, W + pad, C)
+    err = (out[:, :H, :W].float() - ref).abs()
+    assert float((err - (2.0 ** -11) * ref.abs()).max()) <= 2e-5
+    if pad:
+        assert float(out[:, H:].abs().max()) == 0.0 and float(out[:, :, W:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("hw", [(16, 32), (34, 50), (64, 128)])
 def test_first_conv_mish_on_raw_pairs(hw):
     """enc.0.conv_a fused with Split(2), frame stacking and TF 'SAME' stride-2 padding vs torch."""
