@@ -308,6 +308,11 @@ int qpwc_conv3x3s2_mish_c_fwd(const void* x_padded, const void* weight, const vo
 int qpwc_upconv4x4s2_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                               int C, int F, int64_t out_pixel_stride, void* stream);
 
+/* The same layer for fp16 storage (BASELINE configs[4]): x, weight ((16, F, C)) and out fp16, bias fp32, fp32
+ * accumulation, one rounding at the store; out_pixel_stride in elements (halves), out 8-byte aligned. */
+int qpwc_upconv4x4s2_mish_f16_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                                  int C, int F, int64_t out_pixel_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -693,6 +693,121 @@ int upconv4x4s2_mish_launch(const void* x, const void* weight, const void* bias,
     }
 }
 
+// fp16-storage twin of upconv4x4s2_mish_kernel (BASELINE configs[4]): x, weight ([16 taps][F][C]) and out fp16, bias
+// fp32; the same work split (wave = output parity, workgroup = one block of 16 outputs for a TH x 16 input tile), one
+// v_mfma_f32_16x16x32_f16 per tap, tile row and 32-channel block, weights of the current block in 16 registers with
+// the next block's requested ahead, halo tile in LDS as in conv3x3_mish_f16_kernel.  out_pixel_stride in halves.
+template <int C, int TH>
+__global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __half* __restrict__ x,
+                                                                      const __half* __restrict__ weight,
+                                                                      const float* __restrict__ bias,
+                                                                      __half* __restrict__ out, int H, int W, int F,
+                                                                      int out_pixel_stride, int tiles_x, int tiles_y,
+                                                                      int n_tiles) {
+    constexpr int NQ = C / 8, NKB = C / 32;
+    constexpr int HH = TH + 2, NH = HH * kEcHW;
+    constexpr int NST = (NH * NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __half in_s[NH * C];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int fblk = blockIdx.x / n_tiles;
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * TH;
+    const int fo = 16 * fblk;
+    const __half* xb = x + (int64_t)b * H * W * C;
+    {
+        uint4 st[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            st[it] = (idx < NH * NQ && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                         ? *reinterpret_cast<const uint4*>(xb + ((int64_t)gy * W + gx) * C + 8 * q)
+                         : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            if (idx < NH * NQ) *reinterpret_cast<uint4*>(in_s + hp * C + 8 * f16_slot<C>(q, hp)) = st[it];
+        }
+    }
+    const int dy1 = py ? 1 : -1, dx1 = px ? 1 : -1;
+    const int ky0 = py ? 2 : 1, ky1 = py ? 0 : 3, kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
+    const int kpos[4] = {ky0 * 4 + kx0, ky0 * 4 + kx1, ky1 * 4 + kx0, ky1 * 4 + kx1};
+    const int offy[4] = {0, 0, dy1, dy1}, offx[4] = {0, dx1, 0, dx1};
+    f32x4e acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    f16x8e wv[4], wn[4];
+    auto load_w = [&](f16x8e (&w)[4], int kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            w[t] = *reinterpret_cast<const f16x8e*>(weight + ((int64_t)kpos[t] * F + fo + n) * C + 32 * kb + 8 * g);
+    };
+    load_w(wv, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < TH; ++m) {
+                const int hp = (m + 1 + offy[t]) * kEcHW + n + 1 + offx[t];
+                const f16x8e bv = *reinterpret_cast<const f16x8e*>(in_s + hp * C + 8 * f16_slot<C>(4 * kb + g, hp));
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[t], bv, acc[m], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wv[t] = wn[t];
+    }
+    const int H2 = 2 * H, W2 = 2 * W;
+    __half* ob = out + (int64_t)b * H2 * W2 * out_pixel_stride;
+    const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+    for (int m = 0; m < TH; ++m) {
+        const int gy = Y0 + m, gx = X0 + n;
+        if (gy < H && gx < W) {
+            f16x4e o;
+            o[0] = (_Float16)enc_mishf(acc[m][0] + bq.x);
+            o[1] = (_Float16)enc_mishf(acc[m][1] + bq.y);
+            o[2] = (_Float16)enc_mishf(acc[m][2] + bq.z);
+            o[3] = (_Float16)enc_mishf(acc[m][3] + bq.w);
+            *reinterpret_cast<f16x4e*>(ob + ((int64_t)(2 * gy + py) * W2 + 2 * gx + px) * out_pixel_stride + fo + 4 * g) = o;
+        }
+    }
+}
+
+template <int C, int TH>
+static int upconv_f16_launch_t(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int F,
+                               int out_pixel_stride, hipStream_t s) {
+    const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles * (F / 16) > INT32_MAX) {
+        set_error("upconv4x4s2_mish_f16: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((upconv4x4s2_mish_f16_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), 0, s,
+                       (const __half*)x, (const __half*)weight, (const float*)bias, (__half*)out, H, W, F,
+                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles);
+    return check_launch("upconv4x4s2_mish_f16_kernel");
+}
+
+int upconv4x4s2_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                                int C, int F, int out_pixel_stride, hipStream_t s) {
+    switch (C) {
+        case 64: return upconv_f16_launch_t<64, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 128: return upconv_f16_launch_t<128, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 256: return upconv_f16_launch_t<256, 4>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        default: set_error("upconv4x4s2_mish_f16: C=%d not in {64,128,256}", C); return QPWC_E_SHAPE;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // First encoder layer, enc.0.conv_a (Conv2D 3 -> 16, 3x3, stride 2, 'same', Mish; non_layers.py:402-409)
 // straight from the (B,H,W,6) input pair: Split(2) (pwcnet.py:229), the stacking of both frames on the

@@ -200,7 +200,8 @@ class UpConv(_Weighted):
 
     def _hip_upconv_ok(self, x, skip):
         w = self.p("conv_up.weight")
-        return (self.hip_upconv and self.data_format == CHANNELS_LAST and x.is_cuda and x.dtype == torch.float32 and
+        return (self.hip_upconv and self.data_format == CHANNELS_LAST and x.is_cuda and
+                x.dtype in (torch.float32, torch.float16) and skip.dtype == x.dtype and
                 x.is_contiguous() and x.shape[3] in (64, 128, 256) and w.shape[0] == x.shape[3] and
                 w.shape[1] % 16 == 0 and tuple(w.shape[2:]) == (4, 4) and skip.shape[3] % 4 == 0 and
                 tuple(skip.shape[1:3]) == (2 * x.shape[1], 2 * x.shape[2]))
@@ -210,10 +211,10 @@ class UpConv(_Weighted):
         activation epilogue writes its half straight into the concat buffer."""
         if self._hip_upconv_ok(x, skip):
             # own transposed-convolution kernel: bias + Mish fused, written straight into the concat buffer
-            key = self.prefix + "#taps_up"
+            key = self.prefix + ("#taps_up" if x.dtype == torch.float32 else "#taps_up_f16")
             t = self.params.get(key)
             if t is None:
-                t = self.params[key] = ops.upconv_taps(self.p("conv_up.weight"))
+                t = self.params[key] = ops.upconv_taps(self.p("conv_up.weight"), x.dtype)
             buf = torch.empty(skip.shape[:3] + (t.shape[1] + skip.shape[3],), dtype=x.dtype, device=x.device)
             nch = int(hip_chunks)
             if nch > 1 and x.shape[0] % nch == 0:

@@ -709,9 +709,10 @@ def conv3x3s2_mish(x_padded, taps, bias):
     return out
 
 
-def upconv_taps(weight):
-    """torch ConvTranspose2d weight (C_in, F, 4, 4) -> the (16, F, C_in) fp32 layout of qpwc_upconv4x4s2_mish_fwd."""
-    return weight.float().permute(2, 3, 1, 0).reshape(16, weight.shape[1], weight.shape[0]).contiguous()
+def upconv_taps(weight, dtype=torch.float32):
+    """torch ConvTranspose2d weight (C_in, F, 4, 4) -> the (16, F, C_in) layout of qpwc_upconv4x4s2_mish_fwd (fp32) /
+    qpwc_upconv4x4s2_mish_f16_fwd (dtype=torch.float16)."""
+    return weight.to(dtype).permute(2, 3, 1, 0).reshape(16, weight.shape[1], weight.shape[0]).contiguous()
 
 
 def upconv4x4s2_mish_into(x_nhwc, taps, bias, dst):
@@ -720,19 +721,21 @@ def upconv4x4s2_mish_into(x_nhwc, taps, bias, dst):
     concat([up, skip]) (pwcnet.py:186-195).  taps from upconv_taps().  Returns dst."""
     _check_tensor("x", x_nhwc)
     _check_tensor("dst", dst)
-    if x_nhwc.dtype != torch.float32 or dst.dtype != torch.float32 or not x_nhwc.is_contiguous() or \
+    if x_nhwc.dtype not in (torch.float32, torch.float16) or dst.dtype != x_nhwc.dtype or not x_nhwc.is_contiguous() or \
             not dst.is_contiguous():
-        raise ValueError("upconv4x4s2_mish_into needs dense fp32 channels-last tensors")
+        raise ValueError("upconv4x4s2_mish_into needs dense fp32 / fp16 channels-last tensors of one dtype")
     B, H, W, C = x_nhwc.shape
     F_ = taps.shape[1]
-    if tuple(taps.shape) != (16, F_, C) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
+    if tuple(taps.shape) != (16, F_, C) or taps.dtype != x_nhwc.dtype or not taps.is_contiguous() or \
             bias.numel() != F_ or bias.dtype != torch.float32:
-        raise ValueError("taps must be fp32 (16,F,{}), bias fp32 (F)".format(C))
+        raise ValueError("taps must be (16,F,{}) of the input's dtype, bias fp32 (F)".format(C))
     if tuple(dst.shape[:3]) != (B, 2 * H, 2 * W) or dst.shape[3] < F_:
         raise ValueError("dst must be (B,2H,2W,Ctot) with Ctot >= F")
-    with torch.cuda.device(dst.device), _timed("upconv4x4s2_mish", (B, H, W, C, F_)):
-        rc = _hip.lib().qpwc_upconv4x4s2_mish_fwd(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(), dst.data_ptr(),
-                                                  B, H, W, C, F_, dst.shape[3], _stream(dst))
+    f16 = x_nhwc.dtype == torch.float16
+    fn = _hip.lib().qpwc_upconv4x4s2_mish_f16_fwd if f16 else _hip.lib().qpwc_upconv4x4s2_mish_fwd
+    with torch.cuda.device(dst.device), _timed("upconv4x4s2_mish_f16" if f16 else "upconv4x4s2_mish", (B, H, W, C, F_)):
+        rc = fn(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(), dst.data_ptr(), B, H, W, C, F_, dst.shape[3],
+                _stream(dst))
     _hip.check(rc)
     return dst
 

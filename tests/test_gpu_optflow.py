@@ -313,6 +313,25 @@ def test_upconv4x4s2_mish_into_concat_buffer(C, F, hw):
         ops.upconv4x4s2_mish_into(x.to(DEV), ops.upconv_taps(w.to(DEV)), b.to(DEV), dst[:, :-1].contiguous())
 
 
+@pytest.mark.parametrize("C,F", [(256, 256), (256, 128), (128, 64), (64, 32)])
+@pytest.mark.parametrize("hw", [(8, 16), (5, 19), (16, 32)])
+def test_upconv4x4s2_mish_fp16_storage(C, F, hw):
+    """The fp16-storage twin (qpwc_upconv4x4s2_mish_f16_fwd, BASELINE configs[4]) against fp32 torch on the same
+    fp16-rounded operands: the stored value's rounding (2^-11 relative) plus accumulation-order noise."""
+    rng = np.random.default_rng(C + F + hw[0] + 3)
+    H, W = hw
+    x = _rand(rng, 2, H, W, C).half()
+    w = (_rand(rng, C, F, 4, 4) / np.sqrt(4 * C)).half()
+    b = _rand(rng, F)
+    ref = torch_ref.mish(torch.nn.functional.conv_transpose2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=2, padding=1))
+    ref = ref.permute(0, 2, 3, 1)
+    dst = torch.full((2, 2 * H, 2 * W, F + 24), 7.0, device=DEV, dtype=torch.float16)
+    ops.upconv4x4s2_mish_into(x.to(DEV), ops.upconv_taps(w.to(DEV), torch.float16), b.to(DEV), dst)
+    err = (dst[..., :F].cpu().float() - ref).abs()
+    assert float((err - (2.0 ** -11) * ref.abs()).max()) <= 2e-5
+    assert bool((dst[..., F:] == 7.0).all())
+
+
 def test_split_frames_pad():
     rng = np.random.default_rng(8)
     x = _rand(rng, 3, 10, 12, 6)
