@@ -288,6 +288,11 @@ int qpwc_conv3x3_mish_f16_fwd(const void* x, const void* weight, const void* bia
 int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,
                              int H, int W, int layout, void* stream);
 
+/* The same layer for fp16 storage (BASELINE configs[4]): pairs and out fp16, weight and bias fp32 as above (the
+ * 27-term products are exact in fp32), one rounding at the store; pairs 4-byte, out 8-byte aligned. */
+int qpwc_first_conv_mish_f16_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,
+                                 int H, int W, int layout, void* stream);
+
 /* conv_a of the second encoder level: Conv2D(16 -> 32, 3x3, stride 2, padding='same', activation='Mish')
  * (non_layers.py:402-409) on the zero-bordered output of qpwc_conv3x3_mish_fwd (pad 1, 1):
  * x_padded (B, H+1, W+1, 16) fp32 with H, W even (row H and column W zero = TensorFlow's 'SAME' padding)

@@ -80,7 +80,7 @@ int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, voi
 int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s);
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
-                           int layout, hipStream_t s);
+                           int layout, int dtype, hipStream_t s);
 int conv3x3s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                           hipStream_t s);
 int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dtype, hipStream_t s);
@@ -563,7 +563,20 @@ int qpwc_first_conv_mish_fwd(const void* pairs, const void* weight, const void* 
         return fail(QPWC_E_ALIGN, "pairs must be 8-byte, bias and out 16-byte aligned");
     if (overlaps(out, (size_t)2 * B * (H / 2) * (W / 2) * 16 * 4, pairs, (size_t)B * H * W * 6 * 4))
         return fail(QPWC_E_ALIAS, "out overlaps pairs");
-    return first_conv_mish_launch(pairs, weight, bias, out, B, H, W, layout, (hipStream_t)stream);
+    return first_conv_mish_launch(pairs, weight, bias, out, B, H, W, layout, QPWC_F32, (hipStream_t)stream);
+}
+
+int qpwc_first_conv_mish_f16_fwd(const void* pairs, const void* weight, const void* bias, void* out, int B,
+                                 int H, int W, int layout, void* stream) {
+    if (!pairs || !weight || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (layout != QPWC_NHWC && layout != QPWC_NCHW) return fail(QPWC_E_LAYOUT, "Unsupported data format : %d", layout);
+    if (B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return fail(QPWC_E_SHAPE, "B=%d H=%d W=%d: H and W must be even and >= 2", B, H, W);
+    if ((uintptr_t)pairs % 4 || (uintptr_t)weight % 4 || (uintptr_t)bias % 16 || (uintptr_t)out % 8)
+        return fail(QPWC_E_ALIGN, "pairs must be 4-byte, bias 16-byte and out 8-byte aligned");
+    if (overlaps(out, (size_t)2 * B * (H / 2) * (W / 2) * 16 * 2, pairs, (size_t)B * H * W * 6 * 2))
+        return fail(QPWC_E_ALIAS, "out overlaps pairs");
+    return first_conv_mish_launch(pairs, weight, bias, out, B, H, W, layout, QPWC_F16, (hipStream_t)stream);
 }
 
 int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,

@@ -34,6 +34,18 @@ __device__ __forceinline__ float enc_mishf(float x) {
 
 typedef float f32x4e __attribute__((ext_vector_type(4)));
 
+// two consecutive elements as fp32 / four fp32 values stored as four elements (one 8- or 16-byte access)
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const __half* p) { return __half22float2(*reinterpret_cast<const __half2*>(p)); }
+__device__ __forceinline__ void st4q(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4q(__half* p, float4 v) {
+    __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);
+    uint2 u;
+    u.x = *reinterpret_cast<unsigned*>(&lo);
+    u.y = *reinterpret_cast<unsigned*>(&hi);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
 constexpr int kEcTH = 8, kEcTW = 16;
 constexpr int kEcHW = kEcTW + 2, kEcNH = (kEcTH + 2) * kEcHW;   // 180 halo pixels
 
@@ -818,10 +830,13 @@ int upconv4x4s2_mish_f16_launch(const void* x, const void* weight, const void* b
 // wave w -> frame w >> 1, output rows 4 (w & 1) .. + 3.   weight: [9 taps][16 out][4] fp32 (slot 3 = 0).
 constexpr int kFcIH = 2 * kEcTH + 1, kFcIW = 2 * kEcTW + 1;   // 17 x 33 input pixels
 
-__global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __restrict__ x,
+// T = __half: the fp16-storage form (BASELINE configs[4]) -- pairs and out fp16, the patch converted to fp32 on its
+// way into LDS (exact), weights / bias / arithmetic as for fp32, one rounding at the store.
+template <typename T>
+__global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const T* __restrict__ x,
                                                                  const float* __restrict__ weight,
                                                                  const float* __restrict__ bias,
-                                                                 float* __restrict__ out, int B, int H, int W,
+                                                                 T* __restrict__ out, int B, int H, int W,
                                                                  int tiles_x, int tiles_y, int in_nchw) {
     __shared__ __attribute__((aligned(16))) float in_s[kFcIH * kFcIW * 6];
     const int tid = threadIdx.x;
@@ -831,15 +846,15 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int X0 = tx * kEcTW, Y0 = ty * kEcTH;           // output coordinates
     const int Ho = H / 2, Wo = W / 2;
-    const float* xb = x + (int64_t)b * H * W * 6;
-    // ---- stage the input patch: rows 2 Y0 .. + 16, columns 2 X0 .. + 32, 6 channels (8-byte pieces) ----
+    const T* xb = x + (int64_t)b * H * W * 6;
+    // ---- stage the input patch: rows 2 Y0 .. + 16, columns 2 X0 .. + 32, 6 channels (pieces of 2 channels) ----
     if (in_nchw) {   // (B,6,H,W) 'channels_first' input: six planes, lanes walk a row of a plane
         for (int idx = tid; idx < 6 * kFcIH * kFcIW; idx += 256) {
             const int c = idx / (kFcIH * kFcIW), r = idx - c * (kFcIH * kFcIW);
             const int row = r / kFcIW, col = r - row * kFcIW;
             const int gy = 2 * Y0 + row, gx = 2 * X0 + col;
             float v = 0.f;
-            if (gy < H && gx < W) v = xb[((int64_t)c * H + gy) * W + gx];
+            if (gy < H && gx < W) v = ld<T>(xb + ((int64_t)c * H + gy) * W + gx);
             in_s[r * 6 + c] = v;
         }
     } else
@@ -847,7 +862,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __
         const int row = idx / (kFcIW * 3), e = idx - row * (kFcIW * 3);   // e = float2 index inside the row
         const int gy = 2 * Y0 + row, gx = 2 * X0 + e / 3;
         float2 v = make_float2(0.f, 0.f);
-        if (gy < H && gx < W) v = *reinterpret_cast<const float2*>(xb + ((int64_t)gy * W + 2 * X0) * 6 + 2 * e);
+        if (gy < H && gx < W) v = ld2(xb + ((int64_t)gy * W + 2 * X0) * 6 + 2 * e);
         *reinterpret_cast<float2*>(in_s + row * (kFcIW * 6) + 2 * e) = v;
     }
     float wv[9];
@@ -857,7 +872,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __
     __syncthreads();
 
     const int f = wave >> 1;
-    float* ob = out + (int64_t)(f * B + b) * Ho * Wo * 16;
+    T* ob = out + (int64_t)(f * B + b) * Ho * Wo * 16;
     f32x4e acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = f32x4e{0.f, 0.f, 0.f, 0.f};
@@ -875,23 +890,28 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const float* __
     for (int r = 0; r < 4; ++r) {
         const int gy = Y0 + 4 * (wave & 1) + r, gx = X0 + n;
         if (gy < Ho && gx < Wo)
-            *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * 16 + 4 * g) =
-                make_float4(enc_mishf(acc[r][0] + bq.x), enc_mishf(acc[r][1] + bq.y), enc_mishf(acc[r][2] + bq.z),
-                            enc_mishf(acc[r][3] + bq.w));
+            st4q(ob + ((int64_t)gy * Wo + gx) * 16 + 4 * g,
+                 make_float4(enc_mishf(acc[r][0] + bq.x), enc_mishf(acc[r][1] + bq.y), enc_mishf(acc[r][2] + bq.z),
+                             enc_mishf(acc[r][3] + bq.w)));
     }
 }
 
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
-                           int layout, hipStream_t s) {
+                           int layout, int dtype, hipStream_t s) {
     const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + kEcTH - 1) / kEcTH;
     const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
     if (nblk > INT32_MAX) {
         set_error("first_conv_mish: too many tiles");
         return QPWC_E_SHAPE;
     }
-    hipLaunchKernelGGL(first_conv_mish_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const float*)x,
-                       (const float*)weight, (const float*)bias, (float*)out, B, H, W, tiles_x, tiles_y,
-                       layout == QPWC_NCHW ? 1 : 0);
+    if (dtype == QPWC_F32)
+        hipLaunchKernelGGL(first_conv_mish_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, s, (const float*)x,
+                           (const float*)weight, (const float*)bias, (float*)out, B, H, W, tiles_x, tiles_y,
+                           layout == QPWC_NCHW ? 1 : 0);
+    else
+        hipLaunchKernelGGL(first_conv_mish_kernel<__half>, dim3((unsigned)nblk), dim3(256), 0, s, (const __half*)x,
+                           (const float*)weight, (const float*)bias, (__half*)out, B, H, W, tiles_x, tiles_y,
+                           layout == QPWC_NCHW ? 1 : 0);
     return check_launch("first_conv_mish_kernel");
 }
 

@@ -327,7 +327,7 @@ class DownConv(_Weighted):
         hh, ww, cc = (pairs.shape[2], pairs.shape[3], pairs.shape[1]) if pf == CHANNELS_FIRST else \
             (pairs.shape[1], pairs.shape[2], pairs.shape[3])
         if not (self.hip_conv and self.data_format == CHANNELS_LAST and pairs.is_cuda and
-                pairs.dtype == torch.float32 and tuple(w.shape) == (16, 3, 3, 3) and
+                pairs.dtype in (torch.float32, torch.float16) and tuple(w.shape) == (16, 3, 3, 3) and
                 hh % 2 == 0 and ww % 2 == 0 and cc == 6):
             return None
         key = self.prefix + "#taps_a"

@@ -669,8 +669,8 @@ def first_conv_mish(pairs, taps, bias, data_format=CHANNELS_LAST):
     _check_tensor("pairs", pairs)
     cf = data_format == CHANNELS_FIRST
     get_axis(data_format)
-    if pairs.shape[1 if cf else 3] != 6 or pairs.dtype != torch.float32 or not pairs.is_contiguous():
-        raise ValueError("pairs must be a dense fp32 (B,H,W,6) / (B,6,H,W) tensor")
+    if pairs.shape[1 if cf else 3] != 6 or pairs.dtype not in (torch.float32, torch.float16) or not pairs.is_contiguous():
+        raise ValueError("pairs must be a dense fp32 / fp16 (B,H,W,6) / (B,6,H,W) tensor")
     if cf:
         B, _, H, W = pairs.shape
     else:
@@ -678,11 +678,11 @@ def first_conv_mish(pairs, taps, bias, data_format=CHANNELS_LAST):
     if tuple(taps.shape) != (9, 16, 4) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
             bias.numel() != 16 or bias.dtype != torch.float32:
         raise ValueError("taps must be fp32 (9,16,4), bias fp32 (16)")
-    out = torch.empty((2 * B, H // 2, W // 2, 16), dtype=torch.float32, device=pairs.device)
+    out = torch.empty((2 * B, H // 2, W // 2, 16), dtype=pairs.dtype, device=pairs.device)
+    fn = _hip.lib().qpwc_first_conv_mish_fwd if pairs.dtype == torch.float32 else _hip.lib().qpwc_first_conv_mish_f16_fwd
     with torch.cuda.device(out.device), _timed("first_conv_mish", (B, H, W, 6)):
-        rc = _hip.lib().qpwc_first_conv_mish_fwd(pairs.data_ptr(), taps.data_ptr(), bias.data_ptr(),
-                                                 out.data_ptr(), B, H, W, _hip.NCHW if cf else _hip.NHWC,
-                                                 _stream(out))
+        rc = fn(pairs.data_ptr(), taps.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+                _hip.NCHW if cf else _hip.NHWC, _stream(out))
     _hip.check(rc)
     return out
 

@@ -164,7 +164,7 @@ class QpwcNet:
         h, w = self.input_shape
         first = self.enc[0].first_layer(inputs, self.data_format)
         if first is None and self._df != self.data_format:
-            inputs = ops.layout_transpose(inputs, self._df)      # (fp16 storage: no planar first-layer kernel)
+            inputs = ops.layout_transpose(inputs, self._df)      # (no first-layer kernel for this input: odd sizes)
         if first is not None:
             # the frames themselves (entry 0 of the reference's feature lists) are not used downstream
             f, padded = inputs, None

@@ -397,6 +397,26 @@ def test_first_conv_mish_on_raw_pairs(hw):
     torch.testing.assert_close(out, ref, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+@pytest.mark.parametrize("hw", [(16, 32), (34, 50)])
+def test_first_conv_mish_fp16_storage(hw, fmt):
+    """enc.0.conv_a on fp16 pairs (qpwc_first_conv_mish_f16_fwd): exact fp32 products of the fp16 inputs, one rounding
+    at the store; both input layouts."""
+    rng = np.random.default_rng(hw[0] + 11)
+    H, W = hw
+    pairs = _rand(rng, 3, H, W, 6).half()
+    w = (_rand(rng, 16, 3, 3, 3) / np.sqrt(27)).half().float()
+    b = _rand(rng, 16)
+    frames = torch.cat([pairs[..., :3], pairs[..., 3:]], dim=0).float().permute(0, 3, 1, 2)
+    ref = torch_ref.mish(torch.nn.functional.conv2d(torch.nn.functional.pad(frames, (0, 1, 0, 1)), w, b,
+                                                    stride=2)).permute(0, 2, 3, 1)
+    x = pairs if fmt == "channels_last" else pairs.permute(0, 3, 1, 2).contiguous()
+    out = ops.first_conv_mish(x.to(DEV), ops.first_conv_taps(w.to(DEV)), b.to(DEV), fmt).cpu()
+    assert out.dtype == torch.float16 and tuple(out.shape) == (6, H // 2, W // 2, 16)
+    err = (out.float() - ref).abs()
+    assert float((err - (2.0 ** -11) * ref.abs()).max()) <= 2e-5
+
+
 @pytest.mark.parametrize("ci", [16, 32, 64, 128])
 @pytest.mark.parametrize("hw", [(16, 32), (34, 50), (64, 128), (8, 16)])
 def test_conv3x3s2_mish_stride2_levels(hw, ci):
