@@ -305,6 +305,11 @@ int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void
 int qpwc_conv3x3s2_mish_c_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
                               int H, int W, int C_in, void* stream);
 
+/* The same layers for fp16 storage (BASELINE configs[4]): x_padded, weight ((9, 2 C_in, C_in)) and out fp16, bias
+ * fp32, fp32 accumulation, one rounding at the store. */
+int qpwc_conv3x3s2_mish_f16_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
+                                int H, int W, int C_in, void* stream);
+
 /* UpConv of the decoder (non_layers.py:196-210): Conv2DTranspose(F, 4x4, strides 2, padding='same') + bias +
  * Mish of x (B,H,W,C), C in {64,128,256}, F % 16 == 0, written into channels [0, F) of `out`
  * (B, 2H, 2W, *) whose pixels are out_pixel_stride floats apart -- with out_pixel_stride = F + C_skip this is

@@ -1147,6 +1147,130 @@ int conv3x3s2_mish_any_launch(const void* x, const void* weight, const void* bia
     }
 }
 
+// fp16-storage twin of the stride-2 kernels (conv_a of encoder levels 2..5, BASELINE configs[4]): x_padded
+// (B, H+1, W+1, CI), weight ([9][2 CI][CI]) and out (B, H/2, W/2, 2 CI) fp16, bias fp32.  TH x 16 output pixels per
+// workgroup; the (2 TH + 1) x 33 input patch sits in LDS with even and odd columns in separate planes, so the taps of
+// 16 neighbouring outputs are 16 consecutive pixels of a plane; pixels of max(CI, 32) halves, chunk swizzle as in
+// conv3x3_mish_f16_kernel.  A wave owns one block of 16 outputs (2 CI = 32: two waves per block, half the rows each)
+// with its weights for 32 input channels in registers; one v_mfma_f32_16x16x32_f16 per tap, row and 32-channel block.
+template <int CI, int TH>
+__global__ __launch_bounds__(256) void conv3x3s2_mish_f16_kernel(const __half* __restrict__ x,
+                                                                const __half* __restrict__ weight,
+                                                                const float* __restrict__ bias,
+                                                                __half* __restrict__ out, int H, int W, int tiles_x,
+                                                                int tiles_y, int n_tiles) {
+    constexpr int CO = 2 * CI;
+    constexpr int CP = CI < 32 ? 32 : CI;
+    constexpr int NQ = CP / 8, NQG = CI / 8, NKB = CP / 32;
+    constexpr int IH = 2 * TH + 1, PW = kEcTW + 1;            // patch rows, pixels per parity-plane row
+    constexpr int NB = CO / 16;                               // output blocks
+    constexpr int WB = NB < 4 ? NB : 4, WR = 4 / WB;          // waves across blocks / across row groups
+    constexpr int RW = TH / WR;                               // rows per wave
+    constexpr int NCH = IH * (2 * kEcTW + 1) * NQ;            // staged chunks
+    constexpr int NST = (NCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __half in_s[2 * IH * PW * CP];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int slice = blockIdx.x / n_tiles;
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * TH;                  // output coordinates
+    const int Hp = H + 1, Wp = W + 1, Ho = H / 2, Wo = W / 2;
+    const __half* xb = x + (int64_t)b * Hp * Wp * CI;
+    {
+        uint4 st[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int q = idx % NQ, pc = idx / NQ;
+            const int row = pc / (2 * kEcTW + 1), col = pc - row * (2 * kEcTW + 1);
+            const int gy = 2 * Y0 + row, gx = 2 * X0 + col;
+            st[it] = (idx < NCH && q < NQG && gy < Hp && gx < Wp)
+                         ? *reinterpret_cast<const uint4*>(xb + ((int64_t)gy * Wp + gx) * CI + 8 * q)
+                         : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int q = idx % NQ, pc = idx / NQ;
+            const int row = pc / (2 * kEcTW + 1), col = pc - row * (2 * kEcTW + 1);
+            const int hp = ((col & 1) * IH + row) * PW + (col >> 1);
+            if (idx < NCH) *reinterpret_cast<uint4*>(in_s + hp * CP + 8 * f16_slot<CP>(q, hp)) = st[it];
+        }
+    }
+    const int blk = WB == 4 ? 4 * slice + wave : (wave % WB);
+    const int r0 = WB == 4 ? 0 : (wave / WB) * RW;
+    const int fo = 16 * blk;
+    f32x4e acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    const bool kvalid = 8 * g < CI;
+    f16x8e wv[9], wn[9];
+    auto load_w = [&](f16x8e (&w)[9], int kb) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            w[tap] = f16x8e{0, 0, 0, 0, 0, 0, 0, 0};
+            if (kvalid) w[tap] = *reinterpret_cast<const f16x8e*>(weight + ((int64_t)tap * CO + fo + n) * CI + 32 * kb + 8 * g);
+        }
+    };
+    load_w(wv, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int hp = ((kx & 1) * IH + 2 * (r0 + r) + ky) * PW + n + (kx >> 1);
+                const f16x8e bv = *reinterpret_cast<const f16x8e*>(in_s + hp * CP + 8 * f16_slot<CP>(4 * kb + g, hp));
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[tap], bv, acc[r], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wv[tap] = wn[tap];
+    }
+    __half* ob = out + (int64_t)b * Ho * Wo * CO;
+    const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int gy = Y0 + r0 + r, gx = X0 + n;
+        if (gy < Ho && gx < Wo)
+            st4q(ob + ((int64_t)gy * Wo + gx) * CO + fo + 4 * g,
+                 make_float4(enc_mishf(acc[r][0] + bq.x), enc_mishf(acc[r][1] + bq.y), enc_mishf(acc[r][2] + bq.z),
+                             enc_mishf(acc[r][3] + bq.w)));
+    }
+}
+
+template <int CI, int TH>
+static int conv3x3s2_mish_f16_launch_t(const void* x, const void* weight, const void* bias, void* out, int B, int H,
+                                       int W, hipStream_t s) {
+    constexpr int NSL = (2 * CI / 16) < 4 ? 1 : (2 * CI / 16) / 4;
+    const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles * NSL > INT32_MAX) {
+        set_error("conv3x3s2_mish_f16: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((conv3x3s2_mish_f16_kernel<CI, TH>), dim3((unsigned)(n_tiles * NSL)), dim3(256), 0, s,
+                       (const __half*)x, (const __half*)weight, (const float*)bias, (__half*)out, H, W, tiles_x,
+                       tiles_y, (int)n_tiles);
+    return check_launch("conv3x3s2_mish_f16_kernel");
+}
+
+int conv3x3s2_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
+                              int CI, hipStream_t s) {
+    switch (CI) {
+        case 16: return conv3x3s2_mish_f16_launch_t<16, 8>(x, weight, bias, out, B, H, W, s);
+        case 32: return conv3x3s2_mish_f16_launch_t<32, 8>(x, weight, bias, out, B, H, W, s);
+        case 64: return conv3x3s2_mish_f16_launch_t<64, 4>(x, weight, bias, out, B, H, W, s);
+        case 128: return conv3x3s2_mish_f16_launch_t<128, 2>(x, weight, bias, out, B, H, W, s);
+        default: set_error("conv3x3s2_mish_f16: C_in=%d not in {16,32,64,128}", CI); return QPWC_E_SHAPE;
+    }
+}
+
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s) {
     const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + kEcTH - 1) / kEcTH;

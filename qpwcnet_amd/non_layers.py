@@ -269,10 +269,10 @@ class DownConv(_Weighted):
         `after_a`: Mish(conv_a(x) + bias) already computed (channels-last), conv_a is skipped."""
         if after_a is None and padded_in is not None and self._hip_s2_ok(padded_in):
             # second level: stride-2 conv + bias + Mish in one HIP launch on the zero-bordered input
-            key = self.prefix + "#taps_a"
+            key = self.prefix + ("#taps_a" if padded_in.dtype == torch.float32 else "#taps_a_f16")
             t = self.params.get(key)
             if t is None:
-                t = self.params[key] = ops.conv3x3_taps(self.p("conv_a.weight"))
+                t = self.params[key] = ops.conv3x3_taps(self.p("conv_a.weight"), padded_in.dtype)
             after_a = ops.conv3x3s2_mish(padded_in, t, self.p32("conv_a.bias"))
         if after_a is not None:
             y = after_a.permute(0, 3, 1, 2)
@@ -309,7 +309,7 @@ class DownConv(_Weighted):
     def _hip_s2_ok(self, padded_in):
         w = self.p("conv_a.weight")
         return (self.hip_conv and self.data_format == CHANNELS_LAST and padded_in.is_cuda and
-                padded_in.dtype == torch.float32 and padded_in.is_contiguous() and
+                padded_in.dtype in (torch.float32, torch.float16) and padded_in.is_contiguous() and
                 padded_in.shape[3] in (16, 32, 64, 128) and
                 tuple(w.shape) == (2 * padded_in.shape[3], padded_in.shape[3], 3, 3) and
                 padded_in.shape[1] % 2 == 1 and padded_in.shape[2] % 2 == 1)

@@ -694,17 +694,18 @@ def conv3x3s2_mish(x_padded, taps, bias):
     shape (9, 2 C_in, C_in)."""
     _check_tensor("x", x_padded)
     ci = x_padded.shape[3]
-    if x_padded.dtype != torch.float32 or not x_padded.is_contiguous() or ci not in (16, 32, 64, 128):
-        raise ValueError("conv3x3s2_mish needs a dense fp32 (B,H+1,W+1,C) tensor, C in {16,32,64,128}")
+    if x_padded.dtype not in (torch.float32, torch.float16) or not x_padded.is_contiguous() or ci not in (16, 32, 64, 128):
+        raise ValueError("conv3x3s2_mish needs a dense fp32 / fp16 (B,H+1,W+1,C) tensor, C in {16,32,64,128}")
     B, Hp, Wp, _ = x_padded.shape
     H, W = Hp - 1, Wp - 1
-    if tuple(taps.shape) != (9, 2 * ci, ci) or taps.dtype != torch.float32 or not taps.is_contiguous() or \
+    if tuple(taps.shape) != (9, 2 * ci, ci) or taps.dtype != x_padded.dtype or not taps.is_contiguous() or \
             bias.numel() != 2 * ci or bias.dtype != torch.float32:
-        raise ValueError("taps must be fp32 (9,{},{}), bias fp32 ({})".format(2 * ci, ci, 2 * ci))
-    out = torch.empty((B, H // 2, W // 2, 2 * ci), dtype=torch.float32, device=x_padded.device)
-    with torch.cuda.device(out.device), _timed("conv3x3s2_mish", (B, H, W, ci)):
-        rc = _hip.lib().qpwc_conv3x3s2_mish_c_fwd(x_padded.data_ptr(), taps.data_ptr(), bias.data_ptr(),
-                                                  out.data_ptr(), B, H, W, ci, _stream(out))
+        raise ValueError("taps must be (9,{},{}) of the input's dtype, bias fp32 ({})".format(2 * ci, ci, 2 * ci))
+    out = torch.empty((B, H // 2, W // 2, 2 * ci), dtype=x_padded.dtype, device=x_padded.device)
+    f16 = x_padded.dtype == torch.float16
+    fn = _hip.lib().qpwc_conv3x3s2_mish_f16_fwd if f16 else _hip.lib().qpwc_conv3x3s2_mish_c_fwd
+    with torch.cuda.device(out.device), _timed("conv3x3s2_mish_f16" if f16 else "conv3x3s2_mish", (B, H, W, ci)):
+        rc = fn(x_padded.data_ptr(), taps.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, ci, _stream(out))
     _hip.check(rc)
     return out
 

@@ -418,6 +418,25 @@ def test_first_conv_mish_fp16_storage(hw, fmt):
 
 
 @pytest.mark.parametrize("ci", [16, 32, 64, 128])
+@pytest.mark.parametrize("hw", [(16, 32), (34, 50), (8, 16), (2, 2)])
+def test_conv3x3s2_mish_fp16_storage(hw, ci):
+    """conv_a of encoder levels 2..5 for fp16 storage (qpwc_conv3x3s2_mish_f16_fwd) on a zero-bordered fp16 input vs
+    fp32 torch on the same rounded operands."""
+    rng = np.random.default_rng(hw[1] + ci + 5)
+    H, W = hw
+    x = _rand(rng, 2, H, W, ci).half()
+    w = (_rand(rng, 2 * ci, ci, 3, 3) / np.sqrt(9 * ci)).half()
+    b = _rand(rng, 2 * ci)
+    xp = torch.zeros(2, H + 1, W + 1, ci, dtype=torch.float16)
+    xp[:, :H, :W] = x
+    ref = torch_ref.mish(torch.nn.functional.conv2d(xp.float().permute(0, 3, 1, 2), w.float(), b, stride=2)).permute(0, 2, 3, 1)
+    out = ops.conv3x3s2_mish(xp.to(DEV), ops.conv3x3_taps(w.to(DEV), torch.float16), b.to(DEV)).cpu()
+    assert out.dtype == torch.float16 and tuple(out.shape) == (2, H // 2, W // 2, 2 * ci)
+    err = (out.float() - ref).abs()
+    assert float((err - (2.0 ** -11) * ref.abs()).max()) <= 2e-5
+
+
+@pytest.mark.parametrize("ci", [16, 32, 64, 128])
 @pytest.mark.parametrize("hw", [(16, 32), (34, 50), (64, 128), (8, 16)])
 def test_conv3x3s2_mish_stride2_levels(hw, ci):
     """conv_a of encoder levels 2..5 (C_in -> 2 C_in, stride 2, TF 'SAME') on the zero-bordered output of
