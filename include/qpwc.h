@@ -151,6 +151,11 @@ int qpwc_epe_multi_workspace_floats(void);
 int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
                        const int64_t* plane_pixels, int n_levels, void* out_means, void* workspace,
                        void* stream);
+/* The same with a storage dtype per prediction (pred_dtype[i] = QPWC_F32 / QPWC_F16; y_true stays fp32): the
+ * fp16-storage network's flows are converted inside the reduction instead of by a pass of their own. */
+int qpwc_epe_multi_mixed_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
+                             const int64_t* plane_pixels, const int* pred_dtype, int n_levels, void* out_means,
+                             void* workspace, void* stream);
 
 /* cost_volume_to_flow (qpwcnet/core/vis.py:9-34): flow[b,y,x] = (di, dj), the (row, column) displacement
  * of the first maximum over the D = d*d channels of a cost volume: imax = argmax_k, q = sqrt(D),

@@ -26,7 +26,7 @@ SYMBOLS = (
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_optflow_tail_fwd", "qpwc_bias_mish_fwd",
-    "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd",
+    "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd", "qpwc_epe_multi_mixed_fwd",
     "qpwc_cost_volume_to_flow_fwd", "qpwc_sepconv3x3_fwd", "qpwc_sepconv3x3_f16_fwd", "qpwc_bias_mish_pad_fwd", "qpwc_split_frames_pad_fwd",
     "qpwc_invert_flow_fwd", "qpwc_occlusion_fwd", "qpwc_conv3x3_mish_fwd", "qpwc_conv3x3_mish_f16_fwd",
     "qpwc_first_conv_mish_fwd", "qpwc_first_conv_mish_f16_fwd", "qpwc_conv3x3s2_mish_fwd", "qpwc_conv3x3s2_mish_c_fwd", "qpwc_conv3x3s2_mish_f16_fwd", "qpwc_upconv4x4s2_mish_fwd", "qpwc_upconv4x4s2_mish_f16_fwd",
@@ -108,6 +108,9 @@ def lib():
     L.qpwc_epe_multi_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64),
                                      ctypes.POINTER(i64), ci, vp, vp, vp]
     L.qpwc_epe_multi_fwd.restype = ci
+    L.qpwc_epe_multi_mixed_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64),
+                                           ctypes.POINTER(i64), ctypes.POINTER(ci), ci, vp, vp, vp]
+    L.qpwc_epe_multi_mixed_fwd.restype = ci
     L.qpwc_sepconv3x3_fwd.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(i64),
                                       ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.qpwc_sepconv3x3_fwd.restype = ci

@@ -37,7 +37,7 @@ int epe_launch(const float* a, const float* b, float* out, float* ws, int B, int
 
 int epe_multi_workspace_floats();
 int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, const int64_t* plane,
-                     int n_levels, float* out, float* ws, hipStream_t s);
+                     const int* pred_dtype, int n_levels, float* out, float* ws, hipStream_t s);
 int layout_transpose_launch(const void* in, void* out, int B, int H, int W, int C, int to_layout, int dtype,
                             hipStream_t s);
 int copy_pixels_launch(const void* src, void* dst, int B, int H, int W, int64_t row_bytes, int64_t sb, int64_t sy,
@@ -478,7 +478,30 @@ int qpwc_epe_multi_fwd(const void* const* y_true, const void* const* y_pred, con
         if ((uintptr_t)y_true[i] % (planar ? 4 : 8) || (uintptr_t)y_pred[i] % (planar ? 4 : 8))
             return fail(QPWC_E_ALIGN, "flow pointers must be 8-byte (pixels) / 4-byte (planes) aligned");
     }
-    return epe_multi_launch(y_true, y_pred, n_pixels, plane_pixels, n_levels, (float*)out_means,
+    return epe_multi_launch(y_true, y_pred, n_pixels, plane_pixels, nullptr, n_levels, (float*)out_means,
+                            (float*)workspace, (hipStream_t)stream);
+}
+
+int qpwc_epe_multi_mixed_fwd(const void* const* y_true, const void* const* y_pred, const int64_t* n_pixels,
+                             const int64_t* plane_pixels, const int* pred_dtype, int n_levels, void* out_means,
+                             void* workspace, void* stream) {
+    if (!y_true || !y_pred || !n_pixels || !pred_dtype || !out_means || !workspace)
+        return fail(QPWC_E_NULL, "null pointer argument");
+    if (n_levels < 1 || n_levels > 8) return fail(QPWC_E_SHAPE, "n_levels %d outside [1,8]", n_levels);
+    for (int i = 0; i < n_levels; ++i) {
+        if (!y_true[i] || !y_pred[i]) return fail(QPWC_E_NULL, "null flow pointer at level %d", i);
+        if (pred_dtype[i] != QPWC_F32 && pred_dtype[i] != QPWC_F16)
+            return fail(QPWC_E_DTYPE, "level %d: unsupported prediction dtype %d", i, pred_dtype[i]);
+        if (n_pixels[i] <= 0) return fail(QPWC_E_SHAPE, "level %d has no pixels", i);
+        const bool planar = plane_pixels && plane_pixels[i] > 0;
+        if (planar && n_pixels[i] % plane_pixels[i])
+            return fail(QPWC_E_SHAPE, "level %d: %lld pixels are not whole planes of %lld", i,
+                        (long long)n_pixels[i], (long long)plane_pixels[i]);
+        const int pes = pred_dtype[i] == QPWC_F16 ? 2 : 4;
+        if ((uintptr_t)y_true[i] % (planar ? 4 : 8) || (uintptr_t)y_pred[i] % (planar ? pes : 2 * pes))
+            return fail(QPWC_E_ALIGN, "flow pointers must be aligned to a pixel (channels-last) / an element (planes)");
+    }
+    return epe_multi_launch(y_true, y_pred, n_pixels, plane_pixels, pred_dtype, n_levels, (float*)out_means,
                             (float*)workspace, (hipStream_t)stream);
 }
 

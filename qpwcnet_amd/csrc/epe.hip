@@ -72,6 +72,7 @@ struct EpeLevels {
     const float* b[kEpeMaxLevels];
     int64_t npix[kEpeMaxLevels];
     int64_t plane[kEpeMaxLevels];   // 0: (B,H,W,2) pixels; > 0: (B,2,H,W) with H*W = plane
+    int b_f16[kEpeMaxLevels];       // the prediction `b` of this level is fp16 (a: always fp32)
 };
 
 __global__ __launch_bounds__(kEpeThreads) void epe_multi_partial_kernel(EpeLevels lv,
@@ -86,7 +87,40 @@ __global__ __launch_bounds__(kEpeThreads) void epe_multi_partial_kernel(EpeLevel
     const int64_t plane = lv.plane[l];
     // two pixels per 16-byte load, four loads of each array in flight (the finest level is 1 M pixels
     // for 65 k threads: one 8-byte load at a time made this pass latency bound)
-    if (plane > 0) {   // 'channels_first' flows: x and y planes, lanes walk the pixels of a plane
+    if (lv.b_f16[l]) {   // fp16 predictions (fp16-storage network): converted here instead of by a pass of their own
+        const __half* bh = reinterpret_cast<const __half*>(lv.b[l]);
+        const float* af = lv.a[l];
+        if (plane > 0) {
+            for (int64_t i = tid; i < n; i += nthr) {
+                const int64_t img = i / plane, r = i - img * plane;
+                const int64_t o = img * 2 * plane + r;
+                const float dx = af[o] - __half2float(bh[o]), dy = af[o + plane] - __half2float(bh[o + plane]);
+                s += sqrtf(dx * dx + dy * dy);
+            }
+        } else {
+            int64_t i = tid;
+            for (; i + 3 * nthr < n; i += 4 * nthr) {
+                float2 va[4];
+                __half2 vb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    va[k] = a[i + k * nthr];
+                    vb[k] = *reinterpret_cast<const __half2*>(bh + 2 * (i + k * nthr));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float2 fb = __half22float2(vb[k]);
+                    const float dx = va[k].x - fb.x, dy = va[k].y - fb.y;
+                    s += sqrtf(dx * dx + dy * dy);
+                }
+            }
+            for (; i < n; i += nthr) {
+                const float2 va = a[i], fb = __half22float2(*reinterpret_cast<const __half2*>(bh + 2 * i));
+                const float dx = va.x - fb.x, dy = va.y - fb.y;
+                s += sqrtf(dx * dx + dy * dy);
+            }
+        }
+    } else if (plane > 0) {   // 'channels_first' flows: x and y planes, lanes walk the pixels of a plane
         const float* af = lv.a[l];
         const float* bf = lv.b[l];
         for (int64_t i = tid; i < n; i += nthr) {
@@ -150,9 +184,10 @@ __global__ __launch_bounds__(kEpeThreads) void epe_multi_final_kernel(const floa
 int epe_multi_workspace_floats() { return kEpeMaxLevels * kEpeMultiBlocks; }
 
 int epe_multi_launch(const void* const* a, const void* const* b, const int64_t* npix, const int64_t* plane,
-                     int n_levels, float* out, float* ws, hipStream_t s) {
+                     const int* pred_dtype, int n_levels, float* out, float* ws, hipStream_t s) {
     EpeLevels lv;
     for (int i = 0; i < kEpeMaxLevels; ++i) {
+        lv.b_f16[i] = (i < n_levels && pred_dtype && pred_dtype[i] == QPWC_F16) ? 1 : 0;
         lv.a[i] = i < n_levels ? (const float*)a[i] : nullptr;
         lv.b[i] = i < n_levels ? (const float*)b[i] : nullptr;
         lv.npix[i] = i < n_levels ? npix[i] : 0;

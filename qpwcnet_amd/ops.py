@@ -521,16 +521,18 @@ def epe_multi(flows_true, flows_pred, out=None, data_format=CHANNELS_LAST):
         raise ValueError("epe_multi takes 1..8 (true, pred) pairs")
     cf = data_format == CHANNELS_FIRST
     get_axis(data_format)
-    keep, pa, pb, npix, plane = [], [], [], [], []
+    keep, pa, pb, pdt, npix, plane = [], [], [], [], [], []
     for i, (a, b) in enumerate(zip(flows_true, flows_pred)):
         _check_tensor("y_true[%d]" % i, a)
         _check_tensor("y_pred[%d]" % i, b)
         if a.shape != b.shape or a.shape[1 if cf else 3] != 2:
             raise ValueError("level {}: shapes {} / {}".format(i, tuple(a.shape), tuple(b.shape)))
-        a, b = a.float().contiguous(), b.float().contiguous()
+        a = a.float().contiguous()
+        b = b.contiguous() if b.dtype == torch.float16 else b.float().contiguous()   # fp16 predictions as they are
         keep += [a, b]
         pa.append(a.data_ptr())
         pb.append(b.data_ptr())
+        pdt.append(_DTYPES[b.dtype])
         npix.append(a.numel() // 2)
         plane.append(a.shape[2] * a.shape[3] if cf else 0)
     dev = keep[0].device
@@ -541,9 +543,9 @@ def epe_multi(flows_true, flows_pred, out=None, data_format=CHANNELS_LAST):
     elif out.dtype != torch.float32 or out.numel() != n or not out.is_contiguous() or out.device != dev:
         raise ValueError("out must be a dense fp32 vector of {} elements on {}".format(n, dev))
     with torch.cuda.device(dev):
-        rc = L.qpwc_epe_multi_fwd((ctypes.c_void_p * n)(*pa), (ctypes.c_void_p * n)(*pb),
-                                  (ctypes.c_int64 * n)(*npix), (ctypes.c_int64 * n)(*plane), n,
-                                  out.data_ptr(), ws.data_ptr(), _stream(out))
+        rc = L.qpwc_epe_multi_mixed_fwd((ctypes.c_void_p * n)(*pa), (ctypes.c_void_p * n)(*pb),
+                                        (ctypes.c_int64 * n)(*npix), (ctypes.c_int64 * n)(*plane),
+                                        (ctypes.c_int * n)(*pdt), n, out.data_ptr(), ws.data_ptr(), _stream(out))
     _hip.check(rc)
     return out
 

@@ -119,6 +119,9 @@ def test_argument_validation_of_the_next_rows_needs_no_gpu(hip_lib):
     assert L.qpwc_epe_multi_fwd(yt, yp, npix, planes, 9, r, r, None) == _hip.E_SHAPE
     assert L.qpwc_epe_multi_fwd(yt, yp, (i64 * 2)(4, 0), planes, 2, r, r, None) == _hip.E_SHAPE
     assert L.qpwc_epe_multi_fwd(yt, yp, npix, (i64 * 2)(3, 0), 2, r, r, None) == _hip.E_SHAPE   # 4 pixels are not planes of 3
+    assert L.qpwc_epe_multi_mixed_fwd(yt, yp, npix, planes, None, 2, r, r, None) == _hip.E_NULL
+    assert L.qpwc_epe_multi_mixed_fwd(yt, yp, npix, planes, (ci * 2)(0, 9), 2, r, r, None) == _hip.E_DTYPE
+    assert L.qpwc_epe_multi_mixed_fwd(yt, (vp * 2)(q, q + 2), npix, planes, (ci * 2)(0, 1), 2, r, r, None) == _hip.E_ALIGN
 
 
 def test_check_maps_codes_to_reference_exceptions(hip_lib):

@@ -413,6 +413,27 @@ def test_epe_multi_level():
     np.testing.assert_allclose(out2, ref, rtol=1e-5)
 
 
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+def test_epe_multi_level_takes_fp16_predictions_as_they_are(fmt):
+    """qpwc_epe_multi_mixed_fwd: fp16 predictions (the fp16-storage network's flows) are converted inside the
+    reduction -- same result as converting them first; mixed fp16 / fp32 levels in one call."""
+    rng = np.random.default_rng(13)
+    shapes = [(3, 8, 16), (3, 16, 32), (3, 33, 47), (2, 128, 256)]
+    a = [rng.standard_normal(s + (2,)).astype(np.float32) for s in shapes]
+    b = [rng.standard_normal(s + (2,)).astype(np.float16) for s in shapes]
+    if fmt == "channels_first":
+        a = [np.ascontiguousarray(x.transpose(0, 3, 1, 2)) for x in a]
+        b = [np.ascontiguousarray(x.transpose(0, 3, 1, 2)) for x in b]
+    ta, tb = [gpu(x) for x in a], [gpu(x) for x in b]
+    tb[1] = tb[1].float()                                            # one fp32 level among fp16 ones
+    out = ops.epe_multi(ta, tb, data_format=fmt).cpu().numpy()
+    ref = ops.epe_multi(ta, [t.float() for t in tb], data_format=fmt).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-6)
+    axis = 1 if fmt == "channels_first" else 3
+    ref64 = np.asarray([np.sqrt(((x.astype(np.float64) - y.astype(np.float64)) ** 2).sum(axis=axis)).mean() for x, y in zip(a, b)])
+    np.testing.assert_allclose(out, ref64, rtol=1e-5)
+
+
 def test_randomised_shapes_every_kernel_path():
     """Seeded random shapes through every dispatch path (vector kernel, per-wave split-K,
     workgroup-shared, generic) against the C oracle."""
