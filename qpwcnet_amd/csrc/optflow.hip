@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     constexpr int NST = WIDE ? 3 : 6;
     constexpr int SPT = WIDE ? 64 : 32;
     __shared__ __attribute__((aligned(16))) float in_s[kScNH * kScInPS];
-    __shared__ __attribute__((aligned(16))) __half y_s[kScTH * kScTW * kScKC];
+    __shared__ __attribute__((aligned(16))) __half y_s[2 * kScTH * kScTW * kScKC];   // double-buffered by step
     __shared__ __attribute__((aligned(16))) __half w_s[F * kScKC];
     __shared__ __attribute__((aligned(16))) float dw_s[9 * kScKC];
     const int tid = threadIdx.x;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     uint2 st2[WIDE ? 1 : NST];
     float dreg[2];
     wreg0 = wreg1 = make_uint4(0, 0, 0, 0);
-    auto fetch = [&](int c0) {
+    auto fetch_in = [&](int c0) {   // inputs and depthwise taps of the step at channel c0: global -> registers
         const int c = c0 + sch;
         if (WIDE) {
             const __half* sb = (const __half*)src.ptr[0] + (int64_t)b * H * W * src.stride[0];
@@ -775,7 +775,14 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
                 for (int it = 0; it < NST; ++it)
                     st2[it] = goff[it] >= 0 ? *reinterpret_cast<const uint2*>(p + (int64_t)goff[it] * ps)
                                             : make_uint2(0, 0);
-            } else {   // short last source (Flow/UpFlow's 2-channel flow): element loads
+            } else if (left == 2 && (ps & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+                // Flow/UpFlow's 2-channel flow: ONE 4-byte load per pixel
+#pragma unroll
+                for (int it = 0; it < NST; ++it)
+                    st2[it] = goff[it] >= 0
+                                  ? make_uint2(*reinterpret_cast<const unsigned*>(p + (int64_t)goff[it] * ps), 0u)
+                                  : make_uint2(0, 0);
+            } else {   // any other short last source: element loads
 #pragma unroll
                 for (int it = 0; it < NST; ++it) {
                     unsigned short h[4] = {0, 0, 0, 0};
@@ -789,19 +796,19 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
                 }
             }
         }
-        {   // pointwise slice: F rows x 4 chunks of 16 B
-            const int f = tid >> 2, q = tid & 3;
-            const __half* wp = pw + (int64_t)f * cpad + c0 + 8 * q;
-            if (F >= 64 || f < F) wreg0 = *reinterpret_cast<const uint4*>(wp);
-            if (F >= 128) wreg1 = *reinterpret_cast<const uint4*>(wp + (int64_t)64 * cpad);
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             dreg[i] = (idx < kScKC * 9 && c0 * 9 + idx < C * 9) ? dw[c0 * 9 + idx] : 0.0f;
         }
     };
-    auto commit = [&]() {
+    auto fetch_w = [&](int c0) {   // pointwise slice: F rows x 4 chunks of 16 B
+        const int f = tid >> 2, q = tid & 3;
+        const __half* wp = pw + (int64_t)f * cpad + c0 + 8 * q;
+        if (F >= 64 || f < F) wreg0 = *reinterpret_cast<const uint4*>(wp);
+        if (F >= 128) wreg1 = *reinterpret_cast<const uint4*>(wp + (int64_t)64 * cpad);
+    };
+    auto commit_in = [&]() {
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
             const int hp = sps + SPT * it;
@@ -825,28 +832,25 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
                 if (WIDE) *reinterpret_cast<float4*>(d + 4) = make_float4(v[NV - 4], v[NV - 3], v[NV - 2], v[NV - 1]);
             }
         }
-        {
-            const int f = tid >> 2, q = tid & 3;
-            __half* wd = w_s + f * kScKC + ((q ^ (((f & 15) >> 2) & 2)) << 3);
-            if (F >= 64 || f < F) *reinterpret_cast<uint4*>(wd) = wreg0;
-            if (F >= 128) *reinterpret_cast<uint4*>(wd + 64 * kScKC) = wreg1;
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             if (idx < kScKC * 9) dw_s[(idx % 9) * kScKC + idx / 9] = dreg[i];
         }
     };
+    auto commit_w = [&]() {
+        const int f = tid >> 2, q = tid & 3;
+        __half* wd = w_s + f * kScKC + ((q ^ (((f & 15) >> 2) & 2)) << 3);
+        if (F >= 64 || f < F) *reinterpret_cast<uint4*>(wd) = wreg0;
+        if (F >= 128) *reinterpret_cast<uint4*>(wd + 64 * kScKC) = wreg1;
+    };
 
     const int cq = tid & 7, strip = tid >> 3;
     const int drow = strip >> 2, dxs = (strip & 3) * 4;
     const int coff = n * kScKC + ((g ^ ((n >> 2) & 2)) << 3);   // halves: row n, chunk g (8 channels)
 
-    fetch(0);
-    for (int c0 = 0; c0 < cpad; c0 += kScKC) {
-        commit();
-        __syncthreads();
-        if (c0 + kScKC < cpad) fetch(c0 + kScKC);
+    constexpr int kYh = kScTH * kScTW * kScKC;
+    auto depthwise = [&](__half* yd) {
         {   // depthwise in fp32: 4 pixels x 4 channels per thread
             float4 wq[9];
 #pragma unroll
@@ -876,15 +880,16 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
             for (int px = 0; px < 4; ++px) {   // 4 halves = half a 16-byte chunk of the pixel's row
                 const int pix = drow * kScTW + dxs + px;
                 const int chunk = cq >> 1;
-                st4(y_s + pix * kScKC + ((chunk ^ (((pix & 15) >> 2) & 2)) << 3) + 4 * (cq & 1), a[px]);
+                st4(yd + pix * kScKC + ((chunk ^ (((pix & 15) >> 2) & 2)) << 3) + 4 * (cq & 1), a[px]);
             }
         }
-        __syncthreads();
+    };
+    auto pointwise = [&](const __half* ys) {
         {   // pointwise: one 16x16x32 matrix instruction per accumulator
             f16x8v yv[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                yv[m] = *reinterpret_cast<const f16x8v*>(y_s + (32 * wave + 16 * m) * kScKC + coff);
+                yv[m] = *reinterpret_cast<const f16x8v*>(ys + (32 * wave + 16 * m) * kScKC + coff);
 #pragma unroll
             for (int ft = 0; ft < NFT; ++ft) {
                 const f16x8v wv = *reinterpret_cast<const f16x8v*>(w_s + 16 * ft * kScKC + coff);
@@ -893,8 +898,33 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
                     acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, yv[m], acc[m][ft], 0, 0, 0);
             }
         }
+    };
+    // Software pipeline, as in the fp32 kernel: the matrix work of step k and the depthwise convolution of step
+    // k + 1 share one barrier interval (y_s double-buffered), inputs are requested two steps ahead of their
+    // matrix work; two barriers per step instead of three serial phases.
+    //   A: y_s[k&1] complete, w_s and in_s free   -> commit weights(k), inputs(k+1)
+    //   B: staged                                 -> prefetch, pointwise(k) || depthwise(k+1)
+    const int nsteps = cpad / kScKC;
+    fetch_in(0);
+    fetch_w(0);
+    commit_in();
+    __syncthreads();
+    if (nsteps > 1) fetch_in(kScKC);
+    depthwise(y_s);
+    for (int k = 0; k + 1 < nsteps; ++k) {
         __syncthreads();
+        commit_w();
+        commit_in();
+        __syncthreads();
+        fetch_w((k + 1) * kScKC);
+        if (k + 2 < nsteps) fetch_in((k + 2) * kScKC);
+        pointwise(y_s + (k & 1) * kYh);
+        depthwise(y_s + ((k + 1) & 1) * kYh);
     }
+    __syncthreads();
+    commit_w();
+    __syncthreads();
+    pointwise(y_s + ((nsteps - 1) & 1) * kYh);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int pix = 32 * wave + 16 * m + n;
