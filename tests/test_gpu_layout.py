@@ -118,6 +118,22 @@ def test_full_network_channels_first_equals_channels_last(hw, batch):
         m_f(x_l)            # wrong layout for the declared format
 
 
+def test_fp16_network_channels_first_equals_channels_last():
+    """The fp16-storage network (config 5's kernels: fp16 first layer on planar pairs, fp16 encoder / decoder / OptFlow
+    kernels) gives the same flows for both declared layouts, bit for bit."""
+    hw, batch = (64, 128), 3
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(batch, hw[0], hw[1], seed=78)
+    x_l = gpu(pairs).half()
+    x_f = x_l.permute(0, 3, 1, 2).contiguous()
+    m_l = build_flower(True, hw, "channels_last", weights=weights, device=DEV, dtype=torch.float16)
+    m_f = build_flower(True, hw, "channels_first", weights=weights, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        f_l, f_f = m_l(x_l), m_f(x_f)
+    for a, b in zip(f_l, f_f):
+        assert b.dtype == a.dtype and torch.equal(b.permute(0, 2, 3, 1), a)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 5, 7, 16), (3, 8, 16, 32), (1, 33, 19, 8), (16, 16, 32, 64)])
 def test_copy_pixels_between_strided_views(shape, dtype):
