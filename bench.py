@@ -3,19 +3,23 @@
 inference, synthetic frames and seeded random-init weights.  Default workload = BASELINE.json
 configs[1] (batch 8 per GPU, 256x512 fp32; configs[2] = the same per-GPU work on 8 GPUs).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W      (N > 1: starts one fresh process per GPU itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 A step = one forward pass of one batch already resident in HBM: encoder / decoder / flow estimator and
 the hot path (5 cost volumes + 4 warps) in the HIP kernels, the wide coarse-level pointwise GEMMs on
 rocBLAS, 6 per-level EPE reductions, and (N > 1) one RCCL all-gather of the 6-float EPE vector.
-Prints ONE JSON line on rank 0.  On one GPU the line also carries `extra_configs`: BASELINE configs[3]
-(batch 16, 1024x2048 fp32) and configs[4] (batch 32, 256x512 fp16) measured the same way, each with
-its own roofline block -- reported beside the headline, never as `value`.
+Prints ONE JSON line (< 4 KB) on rank 0.  On one GPU the line also carries `extra_configs`: BASELINE
+configs[3] (batch 16, 1024x2048 fp32) and configs[4] (batch 32, 256x512 fp16) measured the same way, each
+with its own `value`, `ms_per_step` and `roofline` -- reported beside the headline, never as `value`.
+Everything else that was measured (per-kernel times of the eager step, the other roofline blocks, method
+notes) goes to `bench_detail.json` beside this file (`--detail PATH`), not into the line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -64,6 +68,11 @@ def parse_args(argv=None):
                         "channels_first, app/optical_flow/test_infer.py:52)")
     p.add_argument("--dist-backend", default=None,
                    help="rehearsal only: 'gloo' runs N ranks on ONE GPU (EPE gathered through host memory)")
+    p.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                   help="file that receives everything measured beyond the one JSON line ('' = do not write)")
+    p.add_argument("--stub-forward", action="store_true",
+                   help="TEST HOOK (tests/test_dist_cpu.py): no kernels, no GPU -- the launcher and the timed step "
+                        "loop only, under gloo on CPU tensors; the line it prints is labelled as a rehearsal")
     p.add_argument("--cpu-pairs", type=int, default=2, help="pairs per timed CPU pass of the full net")
     p.add_argument("--cpu-reps", type=int, default=3, help="timed CPU passes of the full net (median reported)")
     return p.parse_args(argv)
@@ -231,6 +240,8 @@ def cpu_baseline(weights, pairs_np, n_pairs, reps, gpu_flows, hw):
     total = time.perf_counter() - t_all
     return {
         "value": n_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample_short": "{} pairs of the batch, full net, torch-CPU restatement, median of {} passes of {:.1f} s "
+                        "(leg {:.0f} s)".format(n_pairs, len(ts), dt, total),
         "sample": "{} pairs of the same batch, full 6-level net, torch-CPU op-for-op restatement (81x "
                   "slice*mul*mean cost volume, gather warp): median of {} passes of {:.1f} s after one "
                   "warm-up; whole cpu_baseline leg {:.0f} s".format(n_pairs, len(ts), dt, total),
@@ -524,20 +535,136 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
     res["roofline"] = blocks.pop("warp_cost_volume_fused" if fused_dom else "cost_volume")
     res["rooflines_other"] = blocks
     res["hot_path"] = hot
+    res["whole_step"] = whole_step_block(res, B, hw, dtype, world)
     return res, (weights, pairs_np, flows)
+
+
+GFLOP_PER_PAIR_256x512 = 8.59   # encoder 3.68 + decoder 1.88 + OptFlow 2.71 + cost volume 0.32
+
+
+def whole_step_block(res, B, hw, dtype, world):
+    """Whole-step arithmetic rate against the dense matrix peak of the dtype: the network's algorithmic
+    flops per pair (scaled with the pixel count) x pairs per step / measured step time."""
+    gflop = GFLOP_PER_PAIR_256x512 * (hw[0] * hw[1]) / (256.0 * 512.0) * B * world
+    tf = gflop / res["ms_per_step"]   # GFLOP / ms = TFLOP/s
+    peak = (F32_MFMA_PEAK_TFS if dtype == "f32" else F16_MFMA_PEAK_TFS) * world
+    return {"gflop_per_step": round(gflop, 2), "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the line has a size budget); everything else unchanged"""
+    if isinstance(x, float):
+        return float("{:.{}g}".format(x, sig))
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+ROOFLINE_LINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_symbol", "kernel",
+                      "algorithmic_bytes_per_launch", "avg_launch_ms", "frac_of_copy_ceiling",
+                      "unfused_pair_ms", "frac_vs_fused_bytes")
+
+
+def compact_roofline(r, keys=ROOFLINE_LINE_KEYS):
+    return {k: _r(r[k]) for k in keys if k in r}
+
+
+def compact_line(full):
+    """The one JSON line: the contract's fields + roofline + cpu_baseline + whole_step + one short object per
+    extra config (LAST, so that a tail of the line shows them).  Everything else stays in bench_detail.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    line = {k: _r(full[k], 7) for k in keep}
+    c = full["config"]
+    line["config"] = {k: c[k] for k in ("workload", "global_batch", "batch_per_gpu", "parallelism", "hipgraph",
+                                        "fused_upflow") if k in c}
+    line["roofline"] = compact_roofline(full["roofline"])
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind")}
+        line["cpu_baseline"]["sample"] = cb["sample_short"]
+    else:
+        line["cpu_baseline"] = None
+    if "per_level_epe_vs_oracle" in full:
+        line["per_level_epe_vs_oracle"] = _r(full["per_level_epe_vs_oracle"], 3)
+    if "serving_throughput" in full:
+        st = full["serving_throughput"]
+        line["serving_throughput"] = {"value": _r(st["value"]), "batches_in_flight": st["batches_in_flight"]}
+    lib = full.get("library") or {}
+    line["library"] = "{} v{}{}".format(lib.get("build"), lib.get("version"), "" if lib.get("product") else " NOT-PRODUCT")
+    line["detail"] = full.get("detail_file")
+    line["whole_step"] = {k: _r(v) for k, v in full["whole_step"].items()}
+    if "extra_configs" in full:
+        ex = []
+        for r in full["extra_configs"]:
+            if "error" in r:
+                ex.append({"config": r["config"]["workload"], "metric": r["metric"], "error": r["error"][:160]})
+                continue
+            ex.append({"config": r["config"]["workload"].split(":")[0], "metric": r["metric"],
+                       "value": _r(r["value"], 7), "unit": r["unit"], "ms_per_step": _r(r["ms_per_step"], 7),
+                       "steps": r["steps"], "dtype": r["dtype"], "batch_per_gpu": r["config"]["batch_per_gpu"],
+                       "fused_upflow": r["config"].get("fused_upflow"),
+                       "roofline": compact_roofline(r["roofline"], (
+                           "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_symbol",
+                           "algorithmic_bytes_per_launch", "avg_launch_ms", "unfused_pair_ms", "frac_vs_fused_bytes")),
+                       "whole_step_frac": _r(r["whole_step"]["frac"])})
+        line["extra_configs"] = ex
+    return line
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh processes (one per GPU) through
+    torch.distributed.run and pass rank 0's line through.  This parent has made NO GPU call (it runs before
+    anything touches torch.cuda) and does not re-exec itself: it waits for the children and returns their
+    exit code, non-zero if any rank failed."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus {} without WORLD_SIZE: launching {}".format(n, " ".join(cmd[1:9])), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse_stub(args):
+    """--stub-forward: the launcher path and THE timed step loop (dist.timed_steps) with a stub forward on CPU
+    tensors under gloo -- what tests/test_dist_cpu.py runs where there is no GPU.  Not a measurement."""
+    world, rank, _ = qdist.init("gloo")
+    gather = qdist.EpeGather(6, "cpu", n_local=args.batch)
+    base = torch.arange(6, dtype=torch.float32)
+
+    def run_step(k):
+        time.sleep(0.002)
+        return base + 10.0 * k + 1000.0 * rank
+
+    elapsed, results = qdist.timed_steps(run_step, gather, args.steps, args.warmup, "cpu")
+    assert len(results) == args.steps
+    per_rank, mean = results[-1]
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL (stub forward, no kernels): launcher + step loop only",
+                          "value": None, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "rehearsal": True,
+                          "last_step_per_rank": per_rank.tolist(), "last_step_mean": mean.tolist()}))
+    if world > 1:
+        qdist.barrier()
+        torch.distributed.destroy_process_group()
+    return 0
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)      # before any GPU call; the children are fresh processes
+    if args.gpus != qdist.env_world()[0]:   # before the rendezvous: a wrong environment must not wait for peers
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, qdist.env_world()[0]))
+    if args.stub_forward:
+        return rehearse_stub(args)
     world, rank, local_rank = qdist.init(args.dist_backend)
     if args.dist_backend == "gloo":
         local_rank = 0  # rehearsal: every rank shares cuda:0
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus {} needs one process per GPU: launch with "
-                             "python -m torch.distributed.run --nproc-per-node {} bench.py ...".format(
-                                 args.gpus, args.gpus))
-        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -575,11 +702,20 @@ def main():
                               "config": {"workload": baseline_config_name(b, (h, w), dt, world)}})
         result["extra_configs"] = extra
     if rank == 0:
-        print(json.dumps(result))
+        result["detail_file"] = None
+        if args.detail:
+            try:
+                with open(args.detail, "w") as f:
+                    json.dump(result, f, indent=1)
+                result["detail_file"] = os.path.relpath(args.detail, ROOT)
+            except OSError as e:
+                print("bench.py: could not write {} ({})".format(args.detail, e), file=sys.stderr)
+        print(json.dumps(compact_line(result), separators=(",", ":")))
     if world > 1:
         qdist.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -947,6 +947,7 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, const void* flo, v
     if (flo && (C % 32 != 0 || reinterpret_cast<uintptr_t>(flo) % 8 || H < 2 || W < 2 ||
                 (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B < 256))
         return 1;
+    if (flo && lds_mode() == 0) return 1;   // (experimental build, QPWC_CV_LDS=0: no fused form on the split-K kernel)
     // 32-bit byte offsets inside one image (buffer descriptors) and 32-bit element offsets
     // inside one output image: larger problems take the 64-bit vector kernel instead
     const int64_t es = dtype == QPWC_F16 ? 2 : 4;

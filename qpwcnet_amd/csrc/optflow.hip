@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 // A short last source (Flow/UpFlow's 2-channel flow: `left` = 1..3 channels from c on) is read
                 // with the SAME 16-byte load, moved back by 4 - left floats so that it ENDS at the source's last
                 // channel (the front of the quad then holds the previous pixel's trailing channels); commit_in()
-                // re-aligns and zero-fills.  The very first pixel of the tensor has nothing in front of it and
-                // reads forward instead (the launcher checks that the tensor holds >= 4 floats past it).
+                // re-aligns and zero-fills.  The first pixels of the tensor have nothing (or too little) in front of them
+                // and read forward instead (the launcher checks that the tensor holds >= 8 floats).
                 // Element loads here made the wave wait for its prefetch in the middle of the matrix phase.
                 const bool full = left >= 4, tail = left > 0 && left < 4;
                 const int back = tail ? 4 - left : 0;
@@ -435,9 +435,11 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                     const bool ok = goff[it] >= 0 && (full || tail);
                     const float* q = ok ? p : kScZeros;
                     unsigned off = ok ? __umul24((unsigned)goff[it], (unsigned)ps) : 0u;
-                    const bool first = b == 0 && goff[it] == 0;
-                    if (ok && tail && !first) off -= (unsigned)back;
-                    st4[it] = *reinterpret_cast<const float4*>(q + (int)off);
+                    // pixels of image 0 that lie fewer than `back` floats behind the tensor's base (pixel 0; pixels
+                    // 1 and 2 of a 1-channel source with stride 1 or 2) would start in front of it: they read forward
+                    const bool fwd = b == 0 && off < (unsigned)back;
+                    if (ok && tail && !fwd) off -= (unsigned)back;
+                    st4[it] = *reinterpret_cast<const float4*>(q + (int)off);   // |off| < 2^31 (launcher); negative for pixel 0 of image b > 0
                 }
             }
         }
@@ -470,11 +472,13 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 left = (c < e0 ? e0 : (c < e1 ? e1 : nfull)) - c;
             }
             const bool tail = left < 4;
+            const unsigned ps_tail = (unsigned)src.stride[src.ch[2] ? 2 : (src.ch[1] ? 1 : 0)];   // a tail is in the last source
             if (__builtin_amdgcn_ballot_w64(tail) != 0) {
 #pragma unroll
                 for (int it = 0; it < NST; ++it) {
                     const float4 v = st4[it];
-                    const bool fwd = (b == 0 && goff[it] == 0) || goff[it] < 0;   // forward (or zero block): no shift
+                    // forward (or zero block): no shift -- the rule of fetch_in()
+                    const bool fwd = goff[it] < 0 || (b == 0 && __umul24((unsigned)goff[it], ps_tail) < (unsigned)(4 - left));
                     const int sh = fwd ? 0 : 4 - left;
                     const float a0 = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
                     const float a1 = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);
@@ -1044,10 +1048,12 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
         const bool aligned = chans[i] % 4 == 0 && strides[i] % 4 == 0 && reinterpret_cast<uintptr_t>(srcs[i]) % 16 == 0;
         if (!aligned && i + 1 < n_src) vec = false;                  // only the last source may be odd
         if (!aligned && i + 1 == n_src && chans[i] >= 4) vec = false; // ... and only if it is a short tail
-        // the tail quad of the very first pixel is read forward: the tensor must hold 4 floats from there
-        if (!aligned && i + 1 == n_src && (int64_t)B * H * W * strides[i] < 4) vec = false;
-        // the 16-byte path multiplies pixel offset and pixel stride as 24-bit integers into 32 bits
-        if ((int64_t)H * W >= (1 << 24) || strides[i] >= (1 << 24) || (int64_t)H * W * strides[i] >= ((int64_t)1 << 32))
+        // the tail quads of the first pixels (those fewer than 3 floats behind the base) are read forward: the tensor
+        // must hold 4 floats from there
+        if (!aligned && i + 1 == n_src && (int64_t)B * H * W * strides[i] < 8) vec = false;
+        // the 16-byte path multiplies pixel offset and pixel stride as 24-bit integers into 32 bits and adds the
+        // product as a signed 32-bit element offset
+        if ((int64_t)H * W >= (1 << 24) || strides[i] >= (1 << 24) || (int64_t)H * W * strides[i] >= ((int64_t)1 << 31))
             vec = false;
     }
     const float *fdw = (const float*)dw, *fpw = (const float*)pw, *fb = (const float*)bias;

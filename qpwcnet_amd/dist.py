@@ -114,8 +114,8 @@ class EpeGather:
                 raise RuntimeError("EpeGather: slot {} submitted, slot {} is next".format(slot, k))
         self.slot ^= 1
         if not self.collective:
-            # single process: nothing to exchange and nothing to copy.  A slot result is the payload window
-            # itself (valid until the slot comes round again, two steps later); a vector is kept as a clone.
+            # single process: nothing to exchange.  A slot result is the payload window itself until collect()
+            # clones it (the slot comes round again two steps later); a vector is kept as a clone.
             self.pending.append((None, self.payload[k][:self.L] if slot is not None else local_epe.clone()))
             return
         if slot is None:
@@ -128,6 +128,9 @@ class EpeGather:
             raise RuntimeError("EpeGather: nothing submitted")
         work, buf = self.pending.pop(0)
         if not self.collective:
+            # a slot result is a window of the payload buffer that comes round again two steps later: hand out a
+            # copy, so that a caller who keeps the history (timed_steps' `results`) keeps every step's values
+            buf = buf.clone()
             return buf.unsqueeze(0), buf
         work.wait()
         out = buf.view(self.world, self.L + 1)

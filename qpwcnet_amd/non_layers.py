@@ -430,7 +430,12 @@ class OptFlow(_Weighted):
     def from_sources(self, sources):
         """OptFlow on the virtual concat of `sources` ((B,H,W,Ci) each, channels_last)."""
         if not self.can_use_hip(sources):
-            return self(torch.cat(list(sources), dim=self.axis))
+            y = self(torch.cat(list(sources), dim=self.axis))
+            out_format = getattr(self, "out_format", self.data_format)
+            if out_format != self.data_format:   # a channels_first model on channels-last blocks wants (B,2,h,w)
+                y = y.permute(0, 3, 1, 2) if out_format == CHANNELS_FIRST else y.permute(0, 2, 3, 1)
+                y = y.contiguous()
+            return y
         self._prepare_hip()
         B, H, W = sources[0].shape[:3]
         scale = self.scale if self.scale is not None else float(H ** 2 + W ** 2) ** 0.5

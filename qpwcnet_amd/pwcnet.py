@@ -163,8 +163,10 @@ class QpwcNet:
         the encoder once on the 2B stacked frames [prv; nxt] -> [frames, enc_0 .. enc_4]."""
         h, w = self.input_shape
         first = self.enc[0].first_layer(inputs, self.data_format)
+        split_axis = self.axis
         if first is None and self._df != self.data_format:
             inputs = ops.layout_transpose(inputs, self._df)      # (no first-layer kernel for this input: odd sizes)
+            split_axis = get_axis(self._df)                      # the six channels moved with the transposition
         if first is not None:
             # the frames themselves (entry 0 of the reference's feature lists) are not used downstream
             f, padded = inputs, None
@@ -174,7 +176,7 @@ class QpwcNet:
             padded = ops.split_frames_pad(inputs, 1, 1)
             f = padded[:, :h, :w, :]
         else:
-            f, padded = torch.cat(list(self.split(inputs)), dim=0), None
+            f, padded = torch.cat(torch.chunk(inputs, 2, dim=split_axis), dim=0), None
         encs = [f]
         for li, l in enumerate(self.enc):
             # the activation epilogue of level li lays down the 'SAME' padding level li+1 needs

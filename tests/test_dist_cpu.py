@@ -178,3 +178,46 @@ def test_epe_gather_slot_protocol():
     assert torch.equal(eg.collect()[1], torch.tensor([4.0, 5.0, 6.0]))
     with pytest.raises(ValueError):
         eg.submit(torch.zeros(3), slot=0)
+
+
+def test_single_process_step_loop_keeps_every_steps_result():
+    """with the payload written in place and no process group, collect() used to hand out
+    views of the two payload buffers, so only the last two entries of timed_steps' history were valid."""
+    gather = qdist.EpeGather(6, "cpu", n_local=4)
+    base = torch.arange(6, dtype=torch.float32)
+
+    def run_step(k):
+        s = gather.next_slot()
+        gather.payload_view(s).copy_(base + 10.0 * k)
+        return s
+
+    steps, warmup = 6, 2
+    elapsed, results = qdist.timed_steps(run_step, gather, steps, warmup, "cpu")
+    assert elapsed > 0 and len(results) == steps
+    for i, (per_rank, mean) in enumerate(results):
+        assert torch.equal(mean, base + 10.0 * (warmup + i)) and torch.equal(per_rank[0], mean)
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent (which touches no GPU) starts two
+    fresh ranks through torch.distributed.run, rank 0's line comes back on stdout, the exit code is the
+    children's.  --stub-forward: the real dist.timed_steps loop under gloo with a stub forward (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-forward",
+                        "--steps", "5", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["rehearsal"] is True and d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] is None
+    k = 2 + 5 - 1                                         # the drained last result is the last step's
+    assert d["last_step_per_rank"] == [[10.0 * k + i for i in range(6)], [10.0 * k + 1000.0 + i for i in range(6)]]
+    # a failing rank makes the launcher fail: --gpus 2 inside a WORLD_SIZE=3 environment is refused by every rank
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-forward"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0

@@ -118,6 +118,28 @@ def test_full_network_channels_first_equals_channels_last(hw, batch):
         m_f(x_l)            # wrong layout for the declared format
 
 
+def test_channels_first_model_without_first_layer_kernel_and_with_library_optflow():
+    """a channels_first model on the channels-last blocks (a) when enc.0's first-layer kernel does not
+    apply -- the pairs are transposed and split on the axis of the INTERNAL layout -- and (b) when an OptFlow block
+    falls back to the library composition, whose (B,h,w,2) result must still come out as (B,2,h,w)."""
+    hw, batch = (64, 128), 2
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(batch, hw[0], hw[1], seed=79)
+    x_f = gpu(pairs).permute(0, 3, 1, 2).contiguous()
+    ref = build_flower(True, hw, "channels_first", weights=weights, device=DEV)
+    with torch.no_grad():
+        want = ref(x_f)
+    m = build_flower(True, hw, "channels_first", weights=weights, device=DEV)
+    m.enc[0].hip_conv = False                      # (a): first_layer() -> None
+    m.flow.flow.can_use_hip = lambda sources: False   # (b): coarsest block on the library path
+    with torch.no_grad():
+        got = m(x_f)
+    for lvl, (a, b) in enumerate(zip(want, got)):
+        assert tuple(a.shape) == tuple(b.shape)
+        e = float(torch_ref.epe_error(a.permute(0, 2, 3, 1).cpu(), b.permute(0, 2, 3, 1).cpu()))
+        assert e < TOL, "level {} EPE between the two paths {:.3e}".format(lvl, e)
+
+
 def test_fp16_network_channels_first_equals_channels_last():
     """The fp16-storage network (config 5's kernels: fp16 first layer on planar pairs, fp16 encoder / decoder / OptFlow
     kernels) gives the same flows for both declared layouts, bit for bit."""

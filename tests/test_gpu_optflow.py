@@ -183,6 +183,28 @@ def test_sepconv3x3_fused(chans, F, hw, act):
     torch.testing.assert_close(out_act, torch_ref.mish(ref), rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("tail,stride", [(1, 1), (1, 2), (2, 2), (3, 3), (3, 4), (1, 5)])
+def test_sepconv3x3_fused_short_tail_source(tail, stride):
+    """The 16-byte path reads a short last source (1..3 channels) with a load that ENDS at its last channel;
+    the first pixels of the tensor, which have fewer floats in front of them than that shift, read forward
+    instead.  The tail tensor is placed at the very start of its own allocation (a 1-channel source
+    of pixel stride 1 or 2 used to read in front of the tensor's base for pixels 1 and 2 of image 0)."""
+    rng = np.random.default_rng(10 * tail + stride)
+    B, H, W, F = 2, 9, 13, 16
+    a = _rand(rng, B, H, W, 8)
+    wide = _rand(rng, B, H, W, stride)
+    t = wide[..., :tail]                       # pixel stride `stride`, data pointer = start of the allocation
+    dw = _rand(rng, 8 + tail, 1, 3, 3)
+    pw = _rand(rng, F, 8 + tail, 1, 1) / 3
+    bias = _rand(rng, F)
+    y = torch_ref.depthwise3x3([a, t.contiguous()], dw, False)
+    ref = torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw, bias).permute(0, 2, 3, 1)
+    wide_d = wide.to(DEV)
+    out = ops.sepconv3x3([a.to(DEV), wide_d[..., :tail]], dw.to(DEV), ops.pad_pointwise(pw.to(DEV)),
+                         bias.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, rtol=0, atol=5e-5)
+
+
 @pytest.mark.parametrize("chans,F", [((128,), 64), ((64,), 32), ((32,), 16), ((40,), 128), ((8,), 16), ((12,), 16),
                                      ((84, 32, 2), 128), ((84, 256, 256), 128), ((84, 64, 2), 64)])
 @pytest.mark.parametrize("hw", [(8, 16), (19, 37)])

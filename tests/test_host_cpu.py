@@ -286,3 +286,60 @@ def test_source_hash_and_traffic_file_agree():
     import bench
     val, src = bench.load_traffic("cost_volume_L4_bytes_per_launch")
     assert (val is not None) == (t["kernel_source_sha256"] == h), src
+
+
+def test_bench_line_fits_the_drivers_window():
+    """the one JSON line must stay < 4 KB and its last 2000 characters (what the driver's
+    record keeps) must hold every extra config's value, ms_per_step and roofline."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    roof = {"bound": "hbm", "achieved": 4422.6165565062165, "peak": 8000.0, "unit": "GB/s", "frac": 0.5528270695632771,
+            "traffic": 156810294.15384614, "traffic_source": "x" * 80, "copy_ceiling_GBs": 6524.7,
+            "frac_of_copy_ceiling": 0.6778251608555776, "kernel": "fused WarpV2+cost volume L4 16x512x1024x32",
+            "kernel_symbol": "cost_volume_mfma_lds_f16_kernel<true>", "algorithmic_bytes_per_launch": 7079985152,
+            "avg_launch_ms": 0.050026841163635254, "unfused_pair_ms": 0.0552796983718872,
+            "frac_vs_fused_bytes": 0.38514492524076654, "method": "y" * 400}
+    ws = {"gflop_per_step": 68.72, "achieved": 56.9012345, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.361789}
+
+    def leg(name, value):
+        return {"metric": "image-pairs/sec at 1024x2048 fp32", "value": value, "unit": "pairs/s", "n_gpus": 1,
+                "steps": 10, "warmup": 3, "ms_per_step": 29.987678, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": name + ": full 6-level PWC-Net (qpwcnet build_flower) inference, batch 16 per "
+                           "GPU, 1024x2048 fp32, channels_last, d=4 cost volume + WarpV2", "global_batch": 16,
+                           "batch_per_gpu": 16, "parallelism": "dp1 (pairs sharded, RCCL all-gather of the 6 "
+                           "per-level EPE)", "hipgraph": True, "fused_upflow": [False, True, True, True],
+                           "epe_payload": "z" * 120},
+                "roofline": dict(roof), "rooflines_other": {"a": dict(roof), "b": dict(roof)},
+                "hot_path": {"kernels_ms": {"k%d" % i: 0.01 * i for i in range(120)}}, "whole_step": dict(ws)}
+    full = leg("BASELINE configs[1]", 6624.861032851855)
+    full.update(cpu_baseline={"value": 1.2473222377051585, "unit": "pairs/s", "cores": 128, "kind": "port",
+                              "sample": "s" * 300, "sample_short": "2 pairs, full net, median of 3 passes"},
+                per_level_epe_vs_oracle=[2.69e-07] * 6, per_level_epe_vs_ground_truth=[1.0] * 6,
+                serving_throughput={"value": 7232.9, "batches_in_flight": 2, "note": "n" * 100},
+                library={"path": "/p", "version": 200, "build": "libqpwc_hip gfx950 product (no environment switches)",
+                         "product": True},
+                detail_file="bench_detail.json",
+                extra_configs=[leg("BASELINE configs[3]", 533.5524), leg("BASELINE configs[4]", 18117.76)])
+    line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "whole_step"):
+        assert k in d
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+    tail = line[-2000:]
+    for v in ("533.5524", "18117.76", '"extra_configs"', '"whole_step"'):
+        assert v in tail
+    assert tail.count('"ms_per_step"') >= 2 and tail.count('"roofline"') >= 2
