@@ -80,6 +80,17 @@ def parse_args(argv=None):
 
 # ---------------------------------------------------------------------------------------------
 # labels: derived from what actually runs
+class _Operand:
+    """shape / dtype carrier of a device tensor for the dispatch rules (they never touch data)"""
+    is_cuda = True
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), dtype
+
+    def dim(self):
+        return len(self.shape)
+
+
 def baseline_config_name(B, hw, dtype, world):
     if hw == (256, 512) and dtype == "f32" and B == 8:
         return "BASELINE configs[1]" if world == 1 else (
@@ -286,7 +297,10 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
 
     def hbm_block(name, symbol, nbytes, ms, traffic_key, extra=None):
         achieved = nbytes / (ms * 1e-3) / 1e9
-        traffic, tsrc = load_traffic(traffic_key) if dtype == "f32" and lvl4[0] == 8 else (None, "not profiled for this shape")
+        # profiled shapes (tools/make_traffic.sh): the L4 launches of BASELINE configs 2, 4 and 5
+        prefix = {("f32", (8, 128, 256)): "", ("f32", (16, 512, 1024)): "c4_", ("f16", (32, 128, 256)): "c5_"}.get(
+            (dtype, tuple(lvl4[:3])))
+        traffic, tsrc = load_traffic(prefix + traffic_key) if prefix is not None else (None, "not profiled for this shape")
         d = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
              "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
@@ -298,7 +312,7 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
 
     # -- cost volume L4: the step's own launch shape (84-float pixels where the fused first OptFlow layer
     # reads them), random inputs, 50 back-to-back launches per round
-    fused4 = bool(up4.fused) and non_layers.fused_front_end_applies(prv, flo)
+    fused4 = bool(up4.fuses(prv, flo))
     cv_ms = replay_launches(lambda: ops.cost_volume_into(prv, nxt, cbuf, 0))
     sym_by_level = {"L4": cv_ms}
     for lv in (3, 2, 1, 0):
@@ -339,7 +353,7 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
         unf = cost_volume_bytes(*lvl4, esize) + warp_bytes(*lvl4, esize)
         fb = fused_front_bytes(*lvl4, esize)
         in_step = ktimes.get(key_fcv)
-        mfma_fused = non_layers.fused_front_end_applies(prv, flo)
+        mfma_fused = non_layers.fused_kernel_applies(prv)
         out["warp_cost_volume_fused"] = hbm_block(
             "fused WarpV2+cost volume L4 {}".format("x".join(map(str, lvl4))),
             ("cost_volume_mfma_lds_kernel<true>" if dtype == "f32" else "cost_volume_mfma_lds_f16_kernel<true>")
@@ -485,8 +499,8 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
             "epe_payload": ("written by the captured EPE reduction (two graphs over one memory pool, replayed "
                             "alternately; no per-step copy)" if graphs is not None and in_place else "copied per step"),
             # levels L1..L4 whose UpFlow runs WarpV2 + cost volume as one launch
-            "fused_upflow": [bool(u.fused) and
-                             B * (((hw[0] >> (4 - i)) + 7) // 8) * (((hw[1] >> (4 - i)) + 7) // 8) >= 256
+            "fused_upflow": [bool(u.fuses(_Operand((B, hw[0] >> (4 - i), hw[1] >> (4 - i),
+                                                    synth.level_channels()[i + 1]), tdtype)))
                              for i, u in enumerate(model.upflows)],
             "hip_optflow": True,
             "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",

@@ -203,6 +203,37 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size we accept: the load returns 0
 
+// Region order of the workgroup-shared kernels: column STRIPS of 128 pixels, row-major inside a strip.  An XCD takes a
+// contiguous run of this order (xcd_swizzle) and has ~100 regions in flight: in plain row-major order over a 1024-pixel
+// wide level (BASELINE config 4) that is one whole row of regions, whose 16-row neighbourhood plus the 84-float
+// outputs do not survive in the 4 MB L2 until the next row of regions asks for the shared half again -- measured HBM
+// reads 1.44 x (plain) / 1.9 x (fused) the algorithmic bytes (profiles/r03_pmc_*_c4.txt).  In a 128-pixel strip the
+// regions in flight form a compact patch and the next row of the strip follows within a few workgroups.
+// Levels up to 128 pixels wide keep the old order (one strip).  All scalar arithmetic.
+template <int SW>   // strip width in regions (a power of two)
+__device__ __forceinline__ void region_coords(int region, int regs_x, int regs_y, int& rx, int& ry, int& b) {
+    const int per_img = regs_x * regs_y;
+    b = region / per_img;
+    int i = region - b * per_img;
+    if (regs_x <= SW) {
+        ry = i / regs_x;
+        rx = i - ry * regs_x;
+        return;
+    }
+    const int strip = SW * regs_y, full = regs_x / SW;
+    const int s = i / strip;
+    if (s < full) {
+        i -= s * strip;
+        ry = i / SW;
+        rx = s * SW + (i - ry * SW);
+    } else {
+        const int rem = regs_x - full * SW;
+        i -= full * strip;
+        ry = i / rem;
+        rx = full * SW + (i - ry * rem);
+    }
+}
+
 // Operand fetch of the per-wave kernel, two stages:
 //  (1) COALESCED raw buffer loads (descriptor in SGPRs + 32-bit lane byte offset + scalar
 //      step offset; offsets beyond the descriptor return zero = ZeroPadding2D for free).
@@ -479,7 +510,8 @@ __global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int region = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int rx = region % regs_x, ry = (region / regs_x) % regs_y, b = region / (regs_x * regs_y);
+    int rx, ry, b;
+    region_coords<16>(region, regs_x, regs_y, rx, ry, b);
     const int X0 = rx * 8, Y0 = ry * 8;
 #ifdef QPWC_CV_STAMP
     // diagnostic build only (make ab ABFLAGS=-DQPWC_CV_STAMP): shader-clock stamps of wave 0 of 8 workgroups
@@ -669,6 +701,251 @@ __global__ __launch_bounds__(256, WARP ? QPWC_WARP_OCC : 4) void cost_volume_mfm
 }
 
 // ---------------------------------------------------------------------------
+// 16 x 16 pixel regions (round 3): the same scheme with SIXTEEN waves per workgroup (4 x 4 tiles), one workgroup
+// per CU.  Why: a region's 16 + 8 wide neighbourhood is staged once for 16 tiles, so every nxt pixel is staged by
+// 2.25 workgroups instead of 4 (36 + 16 = 52 block loads per 16 tiles = 3.25 per tile instead of 5) -- for the
+// fused front end (WARP), whose staging step is a 4-corner gather per piece and is bound by the L1's 64 B/clk
+// (round 2's counters: 3.3 x the vector-memory instructions of the unfused kernel, texture addresser the busiest
+// unit), that is 44 % fewer gather instructions and 44 % less L2 -> L1 traffic; at BASELINE config 4's size, where
+// a level's nxt no longer sits in the L2s, it is HBM traffic as well.
+//   pieces : block B = it*8 + (wave >> 1) of the 52-block image, pixel (tid & 127) >> 3, chunk tid & 7;
+//            blocks 0..35 = nxt (bi, bj) = (B / 6, B % 6) of the 24 x 24 neighbourhood, 36..51 = prv tile B - 36.
+//            Waves 0..7 stage 5 nxt + 2 prv pieces per lane and step, waves 8..15 4 + 2 (wave-uniform).
+//   LDS    : 52 x 2 KB staging image (swizzled as above), aliased by the sixteen 9.25 KB output frames (148 KB).
+//   the rest (operand reads, 72 matrix instructions per wave and 32-channel step, frame, store_tile) is the
+//   8 x 8 kernel's code: the result is bit-identical to it.
+constexpr int kR16NxtBlocks = 36, kR16Blocks = 52;
+constexpr int kR16StageBytes = kR16Blocks * 2048;
+constexpr int kR16FrameBytes = 16 * kFrameFloats * 4;
+constexpr int kR16LdsBytes = kR16StageBytes > kR16FrameBytes ? kR16StageBytes : kR16FrameBytes;
+
+template <bool WARP>
+__global__ __launch_bounds__(1024) void cost_volume_mfma_lds16_kernel(
+    const float* __restrict__ prv, const float* __restrict__ nxt, const float* __restrict__ flo,
+    float* __restrict__ out, int H, int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope,
+    float inv_c, int pad84) {
+    QPWC_FLOW_CHAIN_PRIO();
+    __shared__ __attribute__((aligned(16))) char smem[kR16LdsBytes];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int region = xcd_swizzle(blockIdx.x, gridDim.x);
+    int rx, ry, b;
+    region_coords<8>(region, regs_x, regs_y, rx, ry, b);
+    const int X0 = rx * 16, Y0 = ry * 16;
+
+    const int img_bytes = H * W * C * 4;  // (H + 24) * (W + 24) * C * 4 < 2^31, checked on the host
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(prv) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(nxt) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+
+    // ---- staging map ------------------------------------------------------------------------------------
+    const int h = wave >> 1;                       // scalar: block column of a round
+    const bool low = wave < 8;                     // scalar: this wave has a fifth nxt piece
+    const int sn = (tid & 127) >> 3, sc = tid & 7;
+    const int spy = sn >> 2, spx = sn & 3;
+    const int lds_w = h * 2048 + sn * 128 + ((sc ^ (sn >> 1)) << 4);   // + it * 16384
+    const unsigned pixb = (unsigned)C * 4u, rowb = (unsigned)W * pixb;
+    unsigned goffn[5], goffp[2];
+    const int itp = low ? 5 : 4;                   // rounds of this wave's two prv pieces: itp, itp + 1
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int B = it * 8 + h, bi = B / 6, bj = B - 6 * bi;       // scalar
+        const int x = X0 - 4 + 4 * bj + spx;
+        // rows above / below the image leave the descriptor's range by themselves (32-bit modular offsets)
+        const unsigned o = (unsigned)(Y0 - 4 + 4 * bi + spy) * rowb + (unsigned)x * pixb + (unsigned)sc * 16u;
+        goffn[it] = (x >= 0 && x < W) ? o : kOob;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int P = (itp + k) * 8 + h - kR16NxtBlocks;              // prv tile, scalar, 0..15
+        const int x = X0 + 4 * (P & 3) + spx;
+        const unsigned o = (unsigned)(Y0 + 4 * (P >> 2) + spy) * rowb + (unsigned)x * pixb + (unsigned)sc * 16u;
+        goffp[k] = x < W ? o : kOob;
+    }
+    // ---- WARP: lane sc < 5 of a pixel's eight computes the taps of piece sc.  The records (corner offset, two lerp
+    // factors) live in the 45 KB of the frame area that the staging image does not cover, 1 KB per wave, for the whole
+    // step loop: a step reads a piece's record when it issues the piece's gathers, so nothing per piece stays in
+    // registers across the matrix phases (15 registers that spilled at 128 per wave).
+    char* const rec = smem + kR16StageBytes + wave * 1024 + (lane >> 3) * 128;   // 8 records of the lane group
+    if (WARP) {
+        const int B = sc * 8 + h, bi = B / 6, bj = B - 6 * bi;
+        const int yy = Y0 - 4 + 4 * bi + spy, xx = X0 - 4 + 4 * bj + spx;
+        const bool inside = B < kR16NxtBlocks && sc < 5 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float2 f = make_float2(0.f, 0.f);
+        if (inside) f = *reinterpret_cast<const float2*>(flo + ((int64_t)(b * H + yy) * W + xx) * 2);
+        const Taps t = taps_clamp(yy, xx, f.x, f.y, H, W);
+        uint4 r;
+        r.x = inside ? (unsigned)(t.y0 * W + t.x0) * pixb : kOob;   // outside: every corner reads zero
+        r.y = __float_as_uint(t.ax);
+        r.z = __float_as_uint(t.ay);
+        r.w = 0u;
+        *reinterpret_cast<uint4*>(rec + sc * 16) = r;
+        __builtin_amdgcn_wave_barrier();   // same-wave LDS traffic is ordered
+    }
+
+    // ---- operand map (matrix-core layout): lane = pixel n, k-slot g; wave = tile (ti, tj) ----------------
+    const int n = lane & 15, g = lane >> 4;
+    const int ti = wave >> 2, tj = wave & 3;
+    const int lds_r = n * 128;
+    const int sw = n >> 1;
+
+    uint4 tab = load_foff(lane, pad84 ? 84 : 81);
+    f32x4 acc[3][3];
+    const int nsteps = C / 32;
+    auto step = [&](int s, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        const int soff = s * 128;
+        if (WARP) {
+            // three rounds of at most eight loads: pieces (0, 1), (2, 3), then (4 | the two prv pieces) -- with the 36
+            // accumulators live in the later steps that is what 128 registers hold without spilling
+            u32x4 c[2][4];
+            float ax[2], ay[2];
+            auto issue = [&](int it, int q) {
+                const uint4 r = *reinterpret_cast<const uint4*>(rec + it * 16);
+                const unsigned o = r.x + (unsigned)sc * 16u;
+                ax[q] = __uint_as_float(r.y);
+                ay[q] = __uint_as_float(r.z);
+                c[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff, 0);
+                c[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)pixb, 0);
+                c[q][2] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)rowb, 0);
+                c[q][3] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)(rowb + pixb), 0);
+            };
+            auto mix = [&](int q) {
+                Taps t;
+                t.ax = ax[q];
+                t.ay = ay[q];
+                u32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = __float_as_uint(blend<QPWC_WARP_CLAMP>(
+                        t, __uint_as_float(c[q][0][e]), __uint_as_float(c[q][1][e]), __uint_as_float(c[q][2][e]),
+                        __uint_as_float(c[q][3][e])));
+                return v;
+            };
+            if (FIRST) {
+                // no accumulator is live yet: every gather of the step is issued before the first one is used (one
+                // memory round trip instead of three -- with one workgroup per CU nobody else hides them)
+                u32x4 c4[3][4], p0, p1;
+                float ax4[3], ay4[3];
+                auto issue4 = [&](int it, int q) {
+                    const uint4 r = *reinterpret_cast<const uint4*>(rec + it * 16);
+                    const unsigned o = r.x + (unsigned)sc * 16u;
+                    ax4[q] = __uint_as_float(r.y);
+                    ay4[q] = __uint_as_float(r.z);
+                    c4[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff, 0);
+                    c4[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)pixb, 0);
+                    c4[q][2] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)rowb, 0);
+                    c4[q][3] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)(rowb + pixb), 0);
+                };
+                auto mix4 = [&](int q) {
+                    Taps t;
+                    t.ax = ax4[q];
+                    t.ay = ay4[q];
+                    u32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = __float_as_uint(blend<QPWC_WARP_CLAMP>(
+                            t, __uint_as_float(c4[q][0][e]), __uint_as_float(c4[q][1][e]),
+                            __uint_as_float(c4[q][2][e]), __uint_as_float(c4[q][3][e])));
+                    return v;
+                };
+                issue(0, 0);
+                issue(1, 1);
+                issue4(2, 0);
+                issue4(3, 1);
+                if (low) issue4(4, 2);
+                p0 = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[0], soff, 0);
+                p1 = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[1], soff, 0);
+                *reinterpret_cast<u32x4*>(smem + lds_w + 0 * 16384) = mix(0);
+                *reinterpret_cast<u32x4*>(smem + lds_w + 1 * 16384) = mix(1);
+                *reinterpret_cast<u32x4*>(smem + lds_w + 2 * 16384) = mix4(0);
+                *reinterpret_cast<u32x4*>(smem + lds_w + 3 * 16384) = mix4(1);
+                if (low) *reinterpret_cast<u32x4*>(smem + lds_w + 4 * 16384) = mix4(2);
+                *reinterpret_cast<u32x4*>(smem + lds_w + itp * 16384) = p0;
+                *reinterpret_cast<u32x4*>(smem + lds_w + (itp + 1) * 16384) = p1;
+            } else {
+                issue(0, 0);
+                issue(1, 1);
+                __syncthreads();  // previous step's operand reads are done
+                {
+                    const u32x4 v0 = mix(0), v1 = mix(1);
+                    issue(2, 0);
+                    issue(3, 1);
+                    *reinterpret_cast<u32x4*>(smem + lds_w + 0 * 16384) = v0;
+                    *reinterpret_cast<u32x4*>(smem + lds_w + 1 * 16384) = v1;
+                }
+                {
+                    const u32x4 v0 = mix(0), v1 = mix(1);
+                    if (low) issue(4, 0);
+                    c[1][0] = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[0], soff, 0);
+                    c[1][1] = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[1], soff, 0);
+                    *reinterpret_cast<u32x4*>(smem + lds_w + 2 * 16384) = v0;
+                    *reinterpret_cast<u32x4*>(smem + lds_w + 3 * 16384) = v1;
+                }
+                if (low) *reinterpret_cast<u32x4*>(smem + lds_w + 4 * 16384) = mix(0);
+                *reinterpret_cast<u32x4*>(smem + lds_w + itp * 16384) = c[1][0];
+                *reinterpret_cast<u32x4*>(smem + lds_w + (itp + 1) * 16384) = c[1][1];
+            }
+        } else {
+            u32x4 st[5], sp[2];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rn, goffn[it], soff, 0);
+            if (low) st[4] = __builtin_amdgcn_raw_buffer_load_b128(rn, goffn[4], soff, 0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) sp[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[k], soff, 0);
+            if (!FIRST) __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(smem + lds_w + it * 16384) = st[it];
+            if (low) *reinterpret_cast<u32x4*>(smem + lds_w + 4 * 16384) = st[4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4*>(smem + lds_w + (itp + k) * 16384) = sp[k];
+        }
+        if (FIRST) asm volatile("" : "+v"(tab.x), "+v"(tab.y), "+v"(tab.z), "+v"(tab.w));
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int coff = (((4 * u + g) ^ sw) << 4) + lds_r;
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(smem + (kR16NxtBlocks + wave) * 2048 + coff);
+            f32x4 nv[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    nv[i][j] = *reinterpret_cast<const f32x4*>(smem + ((ti + i) * 6 + tj + j) * 2048 + coff);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const f32x4 c0 = (FIRST && u == 0 && t == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nv[i][j][t], pv[t], c0, 0, 0, 0);
+                    }
+        }
+    };
+    step(0, std::true_type{});
+    for (int s = 1; s < nsteps; ++s) step(s, std::false_type{});
+    __syncthreads();  // staging area becomes the sixteen output frames
+
+    float* fr = reinterpret_cast<float*>(smem) + wave * kFrameFloats;
+    {
+        float* dst = fr + n * kFramePS + g * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(dst + 48 * i + 4 * j) = acc[i][j];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
+    if (x0 >= W || y0 >= H) return;
+    float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
+    store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab, pad84 != 0);
+}
+
+// ---------------------------------------------------------------------------
 // fp16 storage (BASELINE configs[4]): same workgroup-shared scheme on the fp16 matrix
 // cores, v_mfma_f32_16x16x32_f16 (fp32 accumulate): one instruction per block per
 // 32-channel step instead of eight, so the kernel is purely bandwidth-bound.
@@ -691,7 +968,8 @@ __global__ __launch_bounds__(256, WARP ? 3 : 4) void cost_volume_mfma_lds_f16_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int region = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int rx = region % regs_x, ry = (region / regs_x) % regs_y, b = region / (regs_x * regs_y);
+    int rx, ry, b;
+    region_coords<16>(region, regs_x, regs_y, rx, ry, b);
     const int X0 = rx * 8, Y0 = ry * 8;
 
     const int img_bytes = H * W * C * 2;
@@ -869,8 +1147,57 @@ static int lds_mode() {
 static constexpr int lds_mode() { return 1; }
 #endif
 
+// Region size policy of the workgroup-shared fp32 kernels (measured, tools/kbench.py --regions):
+// 16 x 16 regions need one workgroup of 16 waves per CU to be worth it.
+#ifndef QPWC_R16_MIN_WARP
+#define QPWC_R16_MIN_WARP 256    // 16 x 16 regions per launch from which the fused front end takes them
+#endif
+#ifndef QPWC_R16_MIN_PLAIN
+#define QPWC_R16_MIN_PLAIN (1 << 30)   // the plain cost volume: never (B=8 L3 19.4 vs 17.6 us, config 4 L1-L3 +5 ... +14 %:
+                                       // its staging is 10 plain loads per lane, not the limiter -- DESIGN.md 4.5)
+#endif
+#ifndef QPWC_CV_R16
+#define QPWC_CV_R16 1   // 0 = never, 1 = by the rule below, 2 = wherever the kernel applies (A/B builds)
+#endif
+static bool use_regions16(int B, int H, int W, int C, bool warp) {
+    const int64_t regs16 = (int64_t)((W + 15) / 16) * ((H + 15) / 16) * B;
+    if (QPWC_CV_R16 == 0 || (int64_t)(H + 24) * (W + 24) * C * 4 >= 0x7fffffff) return false;
+    if (QPWC_CV_R16 == 2) return true;
+    // One workgroup per CU means nothing overlaps a region's staging, matrix and store phases: with a single
+    // 32-channel step (C = 32, the finest level) the three phases are of comparable length and the 8 x 8 kernel's
+    // three workgroups per CU win (B=8 L4: 48.7 vs 52.7 us); from two steps on the staging share grows and the
+    // 16 x 16 regions do (L3, C = 64: 22.3 vs 26.3-27.5 us; config 4's L1-L3: -8 ... -10 %).
+    return C >= 64 && regs16 >= (warp ? QPWC_R16_MIN_WARP : QPWC_R16_MIN_PLAIN);
+}
+
+static int launch_lds16(const float* prv, const float* nxt, const float* flo, float* out, int B, int H, int W, int C,
+                        int64_t ops, float slope, int pad84, hipStream_t s) {
+    const int regs_x = (W + 15) / 16, regs_y = (H + 15) / 16;
+    const int64_t nblk = (int64_t)regs_x * regs_y * B;
+    if (nblk > INT32_MAX || (int64_t)H * W * ops > INT32_MAX) {
+        set_error("image too large for 32-bit tile indexing");
+        return QPWC_E_SHAPE;
+    }
+    const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
+    if (flo) {
+        hipLaunchKernelGGL(cost_volume_mfma_lds16_kernel<true>, dim3((unsigned)nblk), dim3(1024), 0, s, prv, nxt,
+                           flo, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
+        return check_launch("cost_volume_mfma_lds16_kernel<warp>");
+    }
+#if QPWC_R16_MIN_PLAIN < (1 << 30)   // A/B builds only: the plain cost volume measured slower on 16 x 16 regions
+    hipLaunchKernelGGL(cost_volume_mfma_lds16_kernel<false>, dim3((unsigned)nblk), dim3(1024), 0, s, prv, nxt,
+                       (const float*)nullptr, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
+    return check_launch("cost_volume_mfma_lds16_kernel");
+#else
+    set_error("cost volume on 16 x 16 regions: fused front end only in this build");
+    return QPWC_E_SHAPE;
+#endif
+}
+
 static int launch_lds(const float* prv, const float* nxt, const float* flo, float* out, int B, int H, int W, int C,
                       int64_t ops, float slope, int pad84, hipStream_t s) {
+    if (use_regions16(B, H, W, C, flo != nullptr))
+        return launch_lds16(prv, nxt, flo, out, B, H, W, C, ops, slope, pad84, s);
     const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
     const int64_t nblk = (int64_t)regs_x * regs_y * B;
     if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * 4 >= 0x7fffffff ||

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 for (int it = 0; it < NST; ++it) {
                     const float4 v = st4[it];
                     // forward (or zero block): no shift -- the rule of fetch_in()
-                    const bool fwd = goff[it] < 0 || (b == 0 && __umul24((unsigned)goff[it], ps_tail) < (unsigned)(4 - left));
+                    const bool fwd = goff[it] < 0 || (b == 0 && (int)__umul24((unsigned)goff[it], ps_tail) < 4 - left);
                     const int sh = fwd ? 0 : 4 - left;
                     const float a0 = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
                     const float a1 = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);

@@ -545,16 +545,33 @@ def _cost84(prv, nxt, search_range, flo=None):
     return cost
 
 
-def fused_front_end_applies(prv, flo=None, search_range=4):
-    """True where qpwc_warp_cost_volume_fwd runs on the matrix cores (WarpV2 gathered in the staging step of
-    the workgroup-shared cost-volume kernel): channels-last fp32 or fp16 storage, C % 32 == 0, >= 256 regions of 8 x 8
-    pixels -- the same rule as cost_volume_mfma_launch.  tools/kbench.py, B=8: L2 14.4 vs 10.5 + 8.1 us for
-    warp + cost volume, L3 25.9 vs 17.9 + 9.6, L4 48.3 vs 36.1 + 16.9.  Elsewhere (few regions: the per-wave
-    split-K kernel's territory) two launches are faster than the LDS-tiled vector kernel's fused form."""
+# Largest level (bytes of one feature tensor) at which UpFlow fuses WarpV2 into the cost volume.  tools/kbench.py,
+# round 3, us (fused vs cost volume + WarpV2): config 2 (B=8 fp32, 34 MB per level) L2 14.6 vs 19.0, L3 22.5 vs 27.5,
+# L4 50.1 vs 52.4; config 5 (B=32 fp16, 67 MB) L1 14.5 vs 16.1, L2 21.0 vs 27.0, L3 40.0 vs 49.7, L4 127.0 vs 126.3;
+# config 4 (B=16, 1024x2048 fp32) L1 (134 MB) 146 vs 156, but L2 (268 MB) 322 vs 309, L3 (537 MB) 758 vs 684, L4
+# (1.07 GB) 1844 vs 1622: past the size the 256 MB memory-side cache holds, the gather's corner loads run up to 17 %
+# slower per pixel than at 256x512 -- although the launch's HBM traffic is its algorithmic bytes x 1.05
+# (profiles/r03_pmc_warp_cost_volume_L4_c4.txt) -- and the pair wins.
+FUSED_FRONT_END_MAX_BYTES = 192 << 20
+
+
+def fused_kernel_applies(prv, search_range=4):
+    """The C side's eligibility rule of the matrix-core fused kernel (cost_volume_mfma_launch), without the size cut."""
     if not (prv.is_cuda and prv.dtype in (torch.float32, torch.float16) and prv.dim() == 4 and search_range == 4):
         return False
     B, H, W, C = prv.shape
     return C % 32 == 0 and H >= 2 and W >= 2 and B * ((H + 7) // 8) * ((W + 7) // 8) >= 256
+
+
+def fused_front_end_applies(prv, flo=None, search_range=4):
+    """True where UpFlow runs WarpV2 + cost volume as ONE launch (qpwc_warp_cost_volume_fwd on the matrix cores: WarpV2
+    gathered in the staging step of the workgroup-shared cost-volume kernel): channels-last fp32 or fp16 storage,
+    C % 32 == 0, >= 256 regions of 8 x 8 pixels (the C side's rule for that kernel), and a level small enough for the
+    fused launch to beat the pair (FUSED_FRONT_END_MAX_BYTES, measured).  Elsewhere two launches are faster."""
+    if not fused_kernel_applies(prv, search_range):
+        return False
+    B, H, W, C = prv.shape
+    return B * H * W * C * (2 if prv.dtype == torch.float16 else 4) <= FUSED_FRONT_END_MAX_BYTES
 
 
 class UpFlow(_Weighted):
@@ -562,8 +579,9 @@ class UpFlow(_Weighted):
     nxt_w = WarpV2(nxt, flo); cost = cv(prv, nxt_w); OptFlow(concat[cost, prv, flo]).
 
     fused (channels_last): WarpV2 and the cost volume as ONE launch (nxt_w never
-    exists in memory) feeding OptFlow.from_sources like the unfused form.  None (default) / True: wherever
-    the matrix-core fused kernel applies (fused_front_end_applies); False: never."""
+    exists in memory) feeding OptFlow.from_sources like the unfused form.  None (default): wherever the
+    matrix-core fused kernel applies AND beats the pair (fused_front_end_applies, a measured rule); True: wherever
+    it applies; False: never."""
 
     def __init__(self, params, prefix, use_tfa=True, fused=None, hip_optflow=True, *args, **kwargs):
         super().__init__(params, prefix, *args, **kwargs)
@@ -574,11 +592,18 @@ class UpFlow(_Weighted):
         cls = CostVolumeV2 if use_tfa else CostVolume
         self.cost_volume = cls(data_format=self.data_format)
         self.fused = (fused is None or bool(fused)) and self.data_format == CHANNELS_LAST and self.hip_optflow
+        self.fused_forced = fused is True
+
+    def fuses(self, prv, flo=None):
+        """Does this block run WarpV2 + cost volume as one launch for operands like `prv`?"""
+        r = self.cost_volume.search_range
+        return self.fused and (fused_front_end_applies(prv, flo, r) or
+                               (self.fused_forced and fused_kernel_applies(prv, r)))
 
     def __call__(self, inputs):
         prv, nxt, flo = inputs
         r = self.cost_volume.search_range
-        if self.fused and fused_front_end_applies(prv, flo, r):
+        if self.fuses(prv, flo):
             flo32 = flo.to(torch.float32).contiguous()   # coordinates are fp32 whatever the storage dtype
             if self.flow.wants_cost84(prv):
                 cost = _cost84(prv, nxt, r, flo=flo32)

@@ -74,7 +74,7 @@ def test_config5_level_shapes_batch32_fp16(hwc):
     assert torch.equal(buf[..., :81], cv) and float(buf[..., 81:].abs().max()) == 0.0
     # fused WarpV2 + cost volume (the launch UpFlow makes where the matrix-core kernel applies): the gather blends
     # in fp32 and rounds ONCE to fp16 like the WarpV2 kernel's store, so it equals warp -> cost volume bit for bit
-    if non_layers.fused_front_end_applies(prv, flo):
+    if non_layers.fused_kernel_applies(prv):
         fused = torch.full((B, H, W, 84), float("nan"), device=DEV, dtype=torch.float16)
         ops.cost_volume_into(prv, nxt, fused, 0, flo=flo)
         unf = ops.cost_volume(prv, wv)

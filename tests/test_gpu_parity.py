@@ -334,7 +334,7 @@ def test_full_network_fp16_config5():
 
 
 @pytest.mark.parametrize("shape", [(32, 36, 52, 32), (40, 30, 44, 64), (3, 19, 37, 32), (5, 7, 9, 64),
-                                   (2, 12, 20, 16), (1, 4, 4, 256)])
+                                   (2, 12, 20, 16), (1, 4, 4, 256), (2, 70, 290, 32)])   # last: 2 strips + a remainder
 def test_matrix_core_kernels_ragged_edges(shape):
     """H, W not multiples of the 4x4 tile / 8x8 region: workgroup-shared kernel (many
     regions) and per-wave split-K kernel (few tiles), zero padding at every border."""
@@ -350,7 +350,8 @@ def test_matrix_core_kernels_ragged_edges(shape):
     np.testing.assert_allclose(outh, refh, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("shape", [(32, 36, 52, 32), (40, 30, 44, 64), (20, 33, 47, 128), (8, 128, 256, 32)])
+@pytest.mark.parametrize("shape", [(32, 36, 52, 32), (40, 30, 44, 64), (20, 33, 47, 128), (8, 128, 256, 32),
+                                   (32, 36, 52, 64), (30, 33, 47, 128), (2, 150, 290, 32), (8, 40, 290, 64)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
 def test_fused_front_end_on_the_matrix_cores_ragged_edges_and_far_flows(shape, dtype):
     """qpwc_warp_cost_volume_fwd where the workgroup-shared matrix-core kernel takes it (>= 256 regions, C % 32 == 0):
@@ -358,7 +359,7 @@ def test_fused_front_end_on_the_matrix_cores_ragged_edges_and_far_flows(shape, d
     land exactly on the last row / column; every output form (dense 81, 84 with zero pads, strided into a concat
     buffer).  The gather blends with the WarpV2 kernel's own code: the result must equal warp -> cost volume bit for
     bit, and the C oracle within the fp32 / fp16-rounding bound."""
-    assert non_layers.fused_front_end_applies(torch.empty(shape, device=DEV, dtype=dtype), None)
+    assert non_layers.fused_kernel_applies(torch.empty(shape, device=DEV, dtype=dtype))
     B, H, W, C = shape
     g = torch.Generator(device=DEV).manual_seed(H * W + C)
     prv = torch.randn(*shape, device=DEV, generator=g).to(dtype)

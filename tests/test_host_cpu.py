@@ -223,6 +223,12 @@ def test_fused_front_end_rule_mirrors_the_c_side():
     assert not ok(T((8, 128, 256, 32)), search_range=3)
     assert not ok(T((8, 128, 256, 32), cuda=False))
     assert not ok(T((8, 128, 256, 32), torch.float64))
+    # round 3: a measured size cut on top of the kernel's own rule -- BASELINE config 4 (B=16, 1024x2048)
+    kern = non_layers.fused_kernel_applies
+    assert kern(T((16, 512, 1024, 32))) and not ok(T((16, 512, 1024, 32)))     # L4: 1.07 GB, the pair wins
+    assert kern(T((16, 128, 256, 128))) and not ok(T((16, 128, 256, 128)))     # L2: 268 MB, the pair wins by 4 %
+    assert ok(T((16, 64, 128, 256)))                                            # L1: 134 MB, fused wins
+    assert ok(T((32, 128, 256, 32), torch.float16))                             # config 5, L4
 
 
 def test_optflow_layer_fusion_rule():

@@ -26,8 +26,10 @@ passes=(
  "F:WRITE_SIZE"
  "G:GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"
 )
+# PMC_PASSES="E F": only those passes (e.g. the two HBM-traffic counters)
 for p in "${passes[@]}"; do
   name=${p%%:*}; ctrs=${p#*:}
+  if [[ -n "${PMC_PASSES:-}" && " $PMC_PASSES " != *" $name "* ]]; then continue; fi
   timeout -k 10 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out/$name" -- "$@" > "$out/$name.log" 2>&1 || { echo "pass $name failed (see $out/$name.log)"; failed=1; }
 done
 echo "pmc passes done -> $out (failed=$failed)"

@@ -7,7 +7,8 @@ exactly half of the bytes of a wide (16 B/lane) coalesced streaming read -> doub
 streaming stores.  The file is stamped with the sha256 of the kernel sources (qpwcnet_amd._hip.source_sha256):
 bench.py drops `roofline.traffic` when the sources have changed since.
 
-usage: traffic_from_pmc.py <pmc dir> <out.json> <tag> <key>=<kernel substring> [...]"""
+usage: traffic_from_pmc.py <pmc dir> <out.json> <tag> <key>=<kernel substring> [...]
+An existing <out.json> with the same source hash and tag is extended (one call per profiled shape)."""
 import csv
 import glob
 import json
@@ -22,11 +23,20 @@ pairs = [a.split("=", 1) for a in sys.argv[4:]]
 rows = []
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     rows += list(csv.DictReader(open(f)))
+prev = {}
+if os.path.exists(out):
+    try:
+        prev = json.load(open(out))
+    except Exception:  # noqa: BLE001
+        prev = {}
+    if prev.get("kernel_source_sha256") != _hip.source_sha256() or prev.get("tag") != tag:
+        prev = {}
 d = {"kernel_source_sha256": _hip.source_sha256(), "tag": tag,
      "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/cv84_launch.py "
              "(tools/make_traffic.sh); FETCH_SIZE KiB x2 (gfx950 16-B/lane correction), WRITE_SIZE KiB; the "
              "cost-volume launches write 84-float pixels (81 channels + 3 zeroed pads), the algorithmic bytes "
              "count 81"}
+d.update({k: v for k, v in prev.items() if k not in d})
 for key, sub in pairs:
     vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
     for r in rows:
