@@ -947,6 +947,13 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     }
 }
 
+#ifndef QPWC_SC16_STREAM
+#define QPWC_SC16_STREAM 0   // lab note only: make ab ABSRC=optflow ABFLAGS=-DQPWC_SC16_STREAM=1
+#endif
+#if QPWC_SC16_STREAM
+#include "experimental/sepconv_f16_stream.inc"
+#endif
+
 template <int F>
 static void sepconv_f16_dispatch(const DwSrc& d, bool wide, int act, const float* dw, const __half* pw,
                                  const float* bias, __half* out, int H, int W, int C, int cpad, int tiles_x,
@@ -989,6 +996,20 @@ int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64
     const dim3 grid((unsigned)nblk);
     const __half* hp = (const __half*)pw;
     const float *fdw = (const float*)dw, *fb = (const float*)bias;
+#if QPWC_SC16_STREAM
+    // lab note (experimental/sepconv_f16_stream.inc): parity-green, slower -- never in the product build
+    if ((act & 1) == 0 && (int64_t)((W + kS2T - 1) / kS2T) * ((H + kS2T - 1) / kS2T) * B <= INT32_MAX) {
+        const bool oa = (act & 2) != 0;
+        switch (F) {
+            case 128: sepconv_f16_stream_dispatch<128>(d, wide, oa, fdw, hp, fb, (__half*)out, H, W, C, cpad, B, s); break;
+            case 64: sepconv_f16_stream_dispatch<64>(d, wide, oa, fdw, hp, fb, (__half*)out, H, W, C, cpad, B, s); break;
+            case 32: sepconv_f16_stream_dispatch<32>(d, wide, oa, fdw, hp, fb, (__half*)out, H, W, C, cpad, B, s); break;
+            case 16: sepconv_f16_stream_dispatch<16>(d, wide, oa, fdw, hp, fb, (__half*)out, H, W, C, cpad, B, s); break;
+            default: set_error("sepconv3x3_f16: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
+        }
+        return check_launch("sepconv3x3_f16_stream_kernel");
+    }
+#endif
     switch (F) {
         case 128: sepconv_f16_dispatch<128>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
         case 64: sepconv_f16_dispatch<64>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;

@@ -2,7 +2,8 @@
 """Fused SeparableConv2D for fp16 storage at config 5 level shapes (B = 32; L4 and L3, the four OptFlow layers each):
 hipGraph replay timing and bytes moved per second; A/B another build with QPWC_HIP_LIB."""
 import os, sys, torch
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _root); sys.path.insert(0, os.path.join(_root, "tools"))
 from qpwcnet_amd import ops
 from sepbench import timeit
 dev = "cuda:0"
