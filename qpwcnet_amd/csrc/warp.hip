@@ -12,6 +12,8 @@
 // and the store are each contiguous per pixel), flow is read once per lane
 // group from L1.  Compiled with -ffp-contract=off so every multiply/add rounds
 // separately, as in the reference's op-by-op graph.
+#include <type_traits>
+
 #include "common.h"
 
 namespace qpwc {
@@ -21,13 +23,59 @@ struct FloStrides {
     int64_t b, y, x, c;
 };
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void warp_nhwc_vec4_kernel(const T* __restrict__ img,
-                                                             const float* __restrict__ flo,
-                                                             T* __restrict__ out, int B, int H,
-                                                             int W, int C, FloStrides fs) {
-    QPWC_FLOW_CHAIN_PRIO();
-    const int nch = C >> 2;
+// VEC consecutive channels of one pixel as fp32: 16-byte loads for fp32 x 4 and fp16 x 8, 8-byte for fp16 x 4
+template <int VEC>
+struct ChanVec {
+    float v[VEC];
+};
+__device__ __forceinline__ ChanVec<4> ldvec4(const float* p) {
+    const float4 a = ld4(p);
+    return ChanVec<4>{{a.x, a.y, a.z, a.w}};
+}
+__device__ __forceinline__ ChanVec<4> ldvec4(const __half* p) {
+    const float4 a = ld4(p);
+    return ChanVec<4>{{a.x, a.y, a.z, a.w}};
+}
+__device__ __forceinline__ ChanVec<8> ldvec8(const __half* p) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    ChanVec<8> r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&w[i]));
+        r.v[2 * i] = f.x;
+        r.v[2 * i + 1] = f.y;
+    }
+    return r;
+}
+__device__ __forceinline__ void stvec(float* p, const ChanVec<4>& a) {
+    st4(p, make_float4(a.v[0], a.v[1], a.v[2], a.v[3]));
+}
+__device__ __forceinline__ void stvec(__half* p, const ChanVec<4>& a) {
+    st4(p, make_float4(a.v[0], a.v[1], a.v[2], a.v[3]));
+}
+__device__ __forceinline__ void stvec(__half* p, const ChanVec<8>& a) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __half2 h = __floats2half2_rn(a.v[2 * i], a.v[2 * i + 1]);
+        w[i] = *reinterpret_cast<const unsigned*>(&h);
+    }
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <int VEC, typename T>
+__device__ __forceinline__ ChanVec<VEC> ldvec(const T* p) {
+    if constexpr (VEC == 8) return ldvec8(p);
+    else return ldvec4(p);
+}
+
+// VEC = 4: fp32 (16-byte accesses) and fp16 with C % 8 != 0 (8-byte); VEC = 8: fp16 with C % 8 == 0 -- a lane moves
+// 16 bytes per access like the fp32 kernel does (round 3: the fp16 kernel with 8-byte accesses ran at 0.35 of the HBM
+// peak at config 5's L4 against 0.54-0.57 for fp32).  The kernel keeps its round-1 symbol name for VEC = 4.
+template <typename T, int MODE, int VEC>
+__device__ __forceinline__ void warp_nhwc_body(const T* __restrict__ img, const float* __restrict__ flo,
+                                               T* __restrict__ out, int B, int H, int W, int C, FloStrides fs) {
+    const int nch = C / VEC;
     const int64_t total = (int64_t)B * H * W * nch;
     // two independent items per thread and trip: 2 flow reads, then 8 corner gathers in flight
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -49,23 +97,45 @@ __global__ __launch_bounds__(256) void warp_nhwc_vec4_kernel(const T* __restrict
             fx[k] = f[0];
             fy[k] = f[fs.c];
         }
-        float4 tl[2], tr[2], bl[2], br[2];
+        ChanVec<VEC> tl[2], tr[2], bl[2], br[2];
         Taps t[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             t[k] = make_taps<MODE>(y[k], x[k], fx[k], fy[k], H, W);
-            const T* ib = img + (int64_t)b[k] * H * W * C + 4 * ch[k];
-            tl[k] = ld4(ib + ((int64_t)t[k].y0 * W + t[k].x0) * C);
-            tr[k] = ld4(ib + ((int64_t)t[k].y0 * W + t[k].x1) * C);
-            bl[k] = ld4(ib + ((int64_t)t[k].y1 * W + t[k].x0) * C);
-            br[k] = ld4(ib + ((int64_t)t[k].y1 * W + t[k].x1) * C);
+            const T* ib = img + (int64_t)b[k] * H * W * C + VEC * ch[k];
+            tl[k] = ldvec<VEC>(ib + ((int64_t)t[k].y0 * W + t[k].x0) * C);
+            tr[k] = ldvec<VEC>(ib + ((int64_t)t[k].y0 * W + t[k].x1) * C);
+            bl[k] = ldvec<VEC>(ib + ((int64_t)t[k].y1 * W + t[k].x0) * C);
+            br[k] = ldvec<VEC>(ib + ((int64_t)t[k].y1 * W + t[k].x1) * C);
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            if (k == 0 || two)
-                st4(out + (((int64_t)(b[k] * H + y[k]) * W + x[k]) * C + 4 * ch[k]),
-                    blend4<MODE>(t[k], tl[k], tr[k], bl[k], br[k]));
+            if (k == 0 || two) {
+                ChanVec<VEC> o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    o.v[e] = blend<MODE>(t[k], tl[k].v[e], tr[k].v[e], bl[k].v[e], br[k].v[e]);
+                stvec(out + (((int64_t)(b[k] * H + y[k]) * W + x[k]) * C + VEC * ch[k]), o);
+            }
     }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void warp_nhwc_vec4_kernel(const T* __restrict__ img,
+                                                             const float* __restrict__ flo,
+                                                             T* __restrict__ out, int B, int H,
+                                                             int W, int C, FloStrides fs) {
+    QPWC_FLOW_CHAIN_PRIO();
+    warp_nhwc_body<T, MODE, 4>(img, flo, out, B, H, W, C, fs);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void warp_nhwc_half8_kernel(const __half* __restrict__ img,
+                                                              const float* __restrict__ flo,
+                                                              __half* __restrict__ out, int B, int H, int W,
+                                                              int C, FloStrides fs) {
+    QPWC_FLOW_CHAIN_PRIO();
+    warp_nhwc_body<__half, MODE, 8>(img, flo, out, B, H, W, C, fs);
 }
 
 // Generic: any C, both layouts; one thread per element in memory order.
@@ -118,11 +188,15 @@ static int warp_impl(const T* img, const float* flo, T* out, int B, int H, int W
     const bool fast = layout == QPWC_NHWC && C % 4 == 0 &&
                       reinterpret_cast<uintptr_t>(img) % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(out) % 16 == 0;
-    const int64_t total = fast ? (int64_t)B * H * W * (C / 4) : (int64_t)B * H * W * C;
+    const bool half8 = fast && std::is_same<T, __half>::value && C % 8 == 0;
+    const int64_t total = fast ? (int64_t)B * H * W * (C / (half8 ? 8 : 4)) : (int64_t)B * H * W * C;
     // fast path: two items per thread; every CU gets >= 8 workgroups before the grid is halved
     const int64_t want = fast && total >= 2 * 256 * 2048 ? (total + 511) / 512 : (total + 255) / 256;
     const unsigned grid = (unsigned)(want < (1 << 20) ? want : (1 << 20));
-    if (fast)
+    if (half8)
+        hipLaunchKernelGGL((warp_nhwc_half8_kernel<MODE>), dim3(grid), dim3(256), 0, s, (const __half*)img, flo,
+                           (__half*)out, B, H, W, C, fs);
+    else if (fast)
         hipLaunchKernelGGL((warp_nhwc_vec4_kernel<T, MODE>), dim3(grid), dim3(256), 0, s, img, flo,
                            out, B, H, W, C, fs);
     else if (layout == QPWC_NHWC)

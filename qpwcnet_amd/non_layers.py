@@ -195,8 +195,9 @@ class UpConv(_Weighted):
 
     hip_upconv = True
     # the skip half of the concat by qpwc_copy_pixels_fwd instead of tensor.copy_: same step time on the side stream
-    # (tools/skipcopy_ab.py: 1.198 vs 1.195 ms/step), so the library copy stays the default
-    skip_copy_hip = False
+    # (tools/skipcopy_ab.py: 1.198 vs 1.195 ms/step); round 3: the own kernel is the default, so that the only
+    # library launches left on a forward are the two wide pointwise GEMMs of L0 / L1
+    skip_copy_hip = True
 
     def _hip_upconv_ok(self, x, skip):
         w = self.p("conv_up.weight")
@@ -547,7 +548,7 @@ def _cost84(prv, nxt, search_range, flo=None):
 
 # Largest level (bytes of one feature tensor) at which UpFlow fuses WarpV2 into the cost volume.  tools/kbench.py,
 # round 3, us (fused vs cost volume + WarpV2): config 2 (B=8 fp32, 34 MB per level) L2 14.6 vs 19.0, L3 22.5 vs 27.5,
-# L4 50.1 vs 52.4; config 5 (B=32 fp16, 67 MB) L1 14.5 vs 16.1, L2 21.0 vs 27.0, L3 40.0 vs 49.7, L4 127.0 vs 126.3;
+# L4 50.1 vs 52.4; config 5 (B=32 fp16, 67 MB) L1 14.5 vs 16.5, L2 21.0 vs 23.5, L3 40.0 vs 42.7, L4 127 vs 113 (pair);
 # config 4 (B=16, 1024x2048 fp32) L1 (134 MB) 146 vs 156, but L2 (268 MB) 322 vs 309, L3 (537 MB) 758 vs 684, L4
 # (1.07 GB) 1844 vs 1622: past the size the 256 MB memory-side cache holds, the gather's corner loads run up to 17 %
 # slower per pixel than at 256x512 -- although the launch's HBM traffic is its algorithmic bytes x 1.05
@@ -571,6 +572,11 @@ def fused_front_end_applies(prv, flo=None, search_range=4):
     if not fused_kernel_applies(prv, search_range):
         return False
     B, H, W, C = prv.shape
+    if prv.dtype == torch.float16 and C < 64:
+        # a single 32-channel step (the finest level): since the fp16 WarpV2 moves 16 bytes per lane (round 3: config 5
+        # L4 48.5 -> 35.6 us) the pair wins there, 77.8 + 35.6 = 113 us vs 127 fused; from two steps on fused still
+        # wins (L3 40.0 vs 23.0 + 19.7, L2 21.0 vs 12.0 + 11.5, L1 14.5 vs 7.2 + 9.3)
+        return False
     return B * H * W * C * (2 if prv.dtype == torch.float16 else 4) <= FUSED_FRONT_END_MAX_BYTES
 
 

@@ -188,10 +188,11 @@ def test_decoder_concat_uses_the_copy_kernel_and_matches_tensor_copy():
     pairs_np, _ = synth.make_frames(B, hw[0], hw[1], seed=9)
     pairs = torch.from_numpy(pairs_np).to("cuda:0")
     model = build_flower(True, hw, "channels_last", weights=weights, device="cuda:0")
+    assert all(d.skip_copy_hip for d in model.dec)      # round 3: the own copy kernel is the default
     with torch.no_grad():
         a = model(pairs)
         for d in model.dec:
-            d.skip_copy_hip = True
+            d.skip_copy_hip = False                     # the library's tensor.copy_
         b = model(pairs)
     torch.cuda.synchronize()
     assert all(torch.equal(x, y) for x, y in zip(a, b))

@@ -228,7 +228,8 @@ def test_fused_front_end_rule_mirrors_the_c_side():
     assert kern(T((16, 512, 1024, 32))) and not ok(T((16, 512, 1024, 32)))     # L4: 1.07 GB, the pair wins
     assert kern(T((16, 128, 256, 128))) and not ok(T((16, 128, 256, 128)))     # L2: 268 MB, the pair wins by 4 %
     assert ok(T((16, 64, 128, 256)))                                            # L1: 134 MB, fused wins
-    assert ok(T((32, 128, 256, 32), torch.float16))                             # config 5, L4
+    assert kern(T((32, 128, 256, 32), torch.float16)) and not ok(T((32, 128, 256, 32), torch.float16))   # config 5 L4: pair
+    assert ok(T((32, 64, 128, 64), torch.float16))                              # config 5 L3: fused
 
 
 def test_optflow_layer_fusion_rule():
