@@ -138,6 +138,19 @@ def cost_volume_symbol(B, H, W, C, dtype):
     return "cost_volume_mfma_kernel"
 
 
+def fused_front_symbol(B, H, W, C, dtype):
+    """The kernel symbol qpwc_warp_cost_volume_fwd selects where the matrix-core fused kernel applies -- the rules of
+    launch_lds (csrc/cost_volume_mfma.hip): fp32 from two 32-channel steps on: 16 x 16 regions (>= 256 of them); one
+    step: 8 x 16 regions (>= 512); else the 8 x 8 kernel."""
+    if dtype != "f32":
+        return "cost_volume_mfma_lds_f16_kernel<true>"
+    if C >= 64 and ((W + 15) // 16) * ((H + 15) // 16) * B >= 256:
+        return "cost_volume_mfma_lds16_kernel<true>"
+    if C == 32 and ((W + 15) // 16) * ((H + 7) // 8) * B >= 512:
+        return "cost_volume_mfma_lds8x16_warp_kernel"
+    return "cost_volume_mfma_lds_kernel<true>"
+
+
 # ---------------------------------------------------------------------------------------------
 # timing helpers (HIP events on the stream the kernels are launched on = torch's current stream)
 def device_copy_ceiling(dev, mib=512, reps=10):
@@ -356,8 +369,7 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
         mfma_fused = non_layers.fused_kernel_applies(prv)
         out["warp_cost_volume_fused"] = hbm_block(
             "fused WarpV2+cost volume L4 {}".format("x".join(map(str, lvl4))),
-            ("cost_volume_mfma_lds_kernel<true>" if dtype == "f32" else "cost_volume_mfma_lds_f16_kernel<true>")
-            if mfma_fused else "cost_volume_tiled_kernel<fused>",
+            fused_front_symbol(*lvl4, dtype) if mfma_fused else "cost_volume_tiled_kernel<fused>",
             unf, f_ms, "warp_cost_volume_L4_bytes_per_launch",
             {"used_by_the_step_at_L4": fused4, "unfused_pair_ms": cv_ms + w_ms,
              "algorithmic_bytes_basis": "unfused pair: cost volume B*H*W*(2C+81)*e + warp B*H*W*(2C+2)*e (SURVEY 8(d))",

@@ -946,6 +946,169 @@ __global__ __launch_bounds__(1024) void cost_volume_mfma_lds16_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// 8 x 16 pixel regions (round 3), fused front end only: EIGHT waves (2 x 4 tiles) per workgroup, two workgroups per
+// CU.  The 16 x 16 form above needs the whole LDS of a CU, so nothing overlaps a region's gather, matrix and store
+// phases -- fine from two 32-channel steps on, where the gather dominates, but a loss at the finest level (C = 32, one
+// step: 52.7 vs 48.7 us at B=8).  This form keeps two independent workgroups on a CU (64 KB staging / 74 KB frames
+// each) and still stages every nxt pixel 3 x instead of 4 x (24 + 8 = 32 block loads per 8 tiles = 4 per tile).
+//   pieces : block B = it*4 + (wave >> 1), it = 0..7: blocks 0..23 = nxt (bi, bj) = (B / 6, B % 6) of the 16-row x
+//            24-column neighbourhood, 24..31 = prv tile B - 24; every lane stages 6 nxt + 2 prv pieces per step.
+constexpr int kR8NxtBlocks = 24, kR8Blocks = 32;
+constexpr int kR8StageBytes = kR8Blocks * 2048;              // 65536
+constexpr int kR8FrameBytes = 8 * kFrameFloats * 4;          // 75776: the 10 KB past the staging image hold the records
+static_assert(kR8FrameBytes - kR8StageBytes >= 8 * 1024, "records need 1 KB per wave past the staging image");
+
+__global__ __launch_bounds__(512, 2) void cost_volume_mfma_lds8x16_warp_kernel(
+    const float* __restrict__ prv, const float* __restrict__ nxt, const float* __restrict__ flo,
+    float* __restrict__ out, int H, int W, int C, int regs_x, int regs_y, int out_pix_stride, float slope,
+    float inv_c, int pad84) {
+    QPWC_FLOW_CHAIN_PRIO();
+    __shared__ __attribute__((aligned(16))) char smem[kR8FrameBytes];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int region = xcd_swizzle(blockIdx.x, gridDim.x);
+    int rx, ry, b;
+    region_coords<8>(region, regs_x, regs_y, rx, ry, b);
+    const int X0 = rx * 16, Y0 = ry * 8;
+
+    const int img_bytes = H * W * C * 4;  // (H + 16) * (W + 24) * C * 4 < 2^31, checked on the host
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(prv) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(nxt) + (int64_t)b * H * W * C, 0, img_bytes, 0x00020000);
+
+    const int h = wave >> 1;                       // scalar: block of a round
+    const int sn = (tid & 127) >> 3, sc = tid & 7;
+    const int spy = sn >> 2, spx = sn & 3;
+    const int lds_w = h * 2048 + sn * 128 + ((sc ^ (sn >> 1)) << 4);   // + it * 8192
+    const unsigned pixb = (unsigned)C * 4u, rowb = (unsigned)W * pixb;
+    unsigned goffp[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int P = (6 + k) * 4 + h - kR8NxtBlocks;                 // prv tile, scalar, 0..7
+        const int x = X0 + 4 * (P & 3) + spx;
+        const unsigned o = (unsigned)(Y0 + 4 * (P >> 2) + spy) * rowb + (unsigned)x * pixb + (unsigned)sc * 16u;
+        goffp[k] = x < W ? o : kOob;
+    }
+    // lane sc < 6 of a pixel's eight computes the taps of piece sc; the records stay in LDS for the whole step loop
+    char* const rec = smem + kR8StageBytes + wave * 1024 + (lane >> 3) * 128;
+    {
+        const int B = sc * 4 + h, bi = B / 6, bj = B - 6 * bi;
+        const int yy = Y0 - 4 + 4 * bi + spy, xx = X0 - 4 + 4 * bj + spx;
+        const bool inside = sc < 6 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float2 f = make_float2(0.f, 0.f);
+        if (inside) f = *reinterpret_cast<const float2*>(flo + ((int64_t)(b * H + yy) * W + xx) * 2);
+        const Taps t = taps_clamp(yy, xx, f.x, f.y, H, W);
+        uint4 r;
+        r.x = inside ? (unsigned)(t.y0 * W + t.x0) * pixb : kOob;   // outside: every corner reads zero
+        r.y = __float_as_uint(t.ax);
+        r.z = __float_as_uint(t.ay);
+        r.w = 0u;
+        *reinterpret_cast<uint4*>(rec + sc * 16) = r;
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    const int n = lane & 15, g = lane >> 4;
+    const int ti = wave >> 2, tj = wave & 3;
+    const int lds_r = n * 128;
+    const int sw = n >> 1;
+
+    uint4 tab = load_foff(lane, pad84 ? 84 : 81);
+    f32x4 acc[3][3];
+    const int nsteps = C / 32;
+    auto step = [&](int s, auto first) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value;
+        constexpr int PR = FIRST ? 3 : 2;            // pieces per round: no accumulator is live in the first step
+        const int soff = s * 128;
+        u32x4 c[PR][4];
+        float ax[PR], ay[PR];
+        auto issue = [&](int it, int q) __attribute__((always_inline)) {
+            const uint4 r = *reinterpret_cast<const uint4*>(rec + it * 16);
+            const unsigned o = r.x + (unsigned)sc * 16u;
+            ax[q] = __uint_as_float(r.y);
+            ay[q] = __uint_as_float(r.z);
+            c[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff, 0);
+            c[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)pixb, 0);
+            c[q][2] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)rowb, 0);
+            c[q][3] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)(rowb + pixb), 0);
+        };
+        auto mix = [&](int q) __attribute__((always_inline)) {
+            Taps t;
+            t.ax = ax[q];
+            t.ay = ay[q];
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = __float_as_uint(blend<QPWC_WARP_CLAMP>(
+                    t, __uint_as_float(c[q][0][e]), __uint_as_float(c[q][1][e]), __uint_as_float(c[q][2][e]),
+                    __uint_as_float(c[q][3][e])));
+            return v;
+        };
+#pragma unroll
+        for (int q = 0; q < PR; ++q) issue(q, q);
+        if (!FIRST) __syncthreads();  // previous step's operand reads are done
+#pragma unroll
+        for (int it = 0; it < 6; it += PR) {
+            u32x4 v[PR];
+#pragma unroll
+            for (int q = 0; q < PR; ++q) v[q] = mix(q);
+            if (it + PR < 6) {
+#pragma unroll
+                for (int q = 0; q < PR; ++q) issue(it + PR + q, q);
+            } else {   // last round: the two prv pieces ride in the freed registers
+                c[0][0] = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[0], soff, 0);
+                c[0][1] = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[1], soff, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < PR; ++q) *reinterpret_cast<u32x4*>(smem + lds_w + (it + q) * 8192) = v[q];
+        }
+        *reinterpret_cast<u32x4*>(smem + lds_w + 6 * 8192) = c[0][0];
+        *reinterpret_cast<u32x4*>(smem + lds_w + 7 * 8192) = c[0][1];
+        if (FIRST) asm volatile("" : "+v"(tab.x), "+v"(tab.y), "+v"(tab.z), "+v"(tab.w));
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int coff = (((4 * u + g) ^ sw) << 4) + lds_r;
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(smem + (kR8NxtBlocks + wave) * 2048 + coff);
+            f32x4 nv[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    nv[i][j] = *reinterpret_cast<const f32x4*>(smem + ((ti + i) * 6 + tj + j) * 2048 + coff);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const f32x4 c0 = (FIRST && u == 0 && t == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nv[i][j][t], pv[t], c0, 0, 0, 0);
+                    }
+        }
+    };
+    step(0, std::true_type{});
+    for (int s = 1; s < nsteps; ++s) step(s, std::false_type{});
+    __syncthreads();  // staging area (and the records) become the eight output frames
+
+    float* fr = reinterpret_cast<float*>(smem) + wave * kFrameFloats;
+    {
+        float* dst = fr + n * kFramePS + g * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(dst + 48 * i + 4 * j) = acc[i][j];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int x0 = X0 + 4 * tj, y0 = Y0 + 4 * ti;
+    if (x0 >= W || y0 >= H) return;
+    float* ob = out + ((int64_t)(b * H + y0) * W + x0) * out_pix_stride;
+    store_tile<float>(fr, ob, lane, x0, y0, H, W, out_pix_stride, slope, inv_c, (float)C, tab, pad84 != 0);
+}
+
+// ---------------------------------------------------------------------------
 // fp16 storage (BASELINE configs[4]): same workgroup-shared scheme on the fp16 matrix
 // cores, v_mfma_f32_16x16x32_f16 (fp32 accumulate): one instruction per block per
 // 32-channel step instead of eight, so the kernel is purely bandwidth-bound.
@@ -1194,10 +1357,29 @@ static int launch_lds16(const float* prv, const float* nxt, const float* flo, fl
 #endif
 }
 
+#ifndef QPWC_R8X16_ANYC
+#define QPWC_R8X16_ANYC 0     // A/B builds: 8 x 16 regions for every channel count the 16 x 16 form does not take
+#endif
+#ifndef QPWC_R8X16_MIN
+#define QPWC_R8X16_MIN 512    // 8 x 16 regions per launch from which the single-step fused front end takes them (2 per CU)
+#endif
+static int launch_lds8x16_warp(const float* prv, const float* nxt, const float* flo, float* out, int B, int H, int W,
+                               int C, int64_t ops, float slope, int pad84, hipStream_t s) {
+    const int regs_x = (W + 15) / 16, regs_y = (H + 7) / 8;
+    const int64_t nblk = (int64_t)regs_x * regs_y * B;
+    const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
+    hipLaunchKernelGGL(cost_volume_mfma_lds8x16_warp_kernel, dim3((unsigned)nblk), dim3(512), 0, s, prv, nxt, flo, out,
+                       H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
+    return check_launch("cost_volume_mfma_lds8x16_warp_kernel");
+}
+
 static int launch_lds(const float* prv, const float* nxt, const float* flo, float* out, int B, int H, int W, int C,
                       int64_t ops, float slope, int pad84, hipStream_t s) {
     if (use_regions16(B, H, W, C, flo != nullptr))
         return launch_lds16(prv, nxt, flo, out, B, H, W, C, ops, slope, pad84, s);
+    if (flo && (C == 32 || QPWC_R8X16_ANYC) && QPWC_R8X16_MIN > 0 && (int64_t)((W + 15) / 16) * ((H + 7) / 8) * B >= QPWC_R8X16_MIN &&
+        (int64_t)(H + 16) * (W + 24) * C * 4 < 0x7fffffff && (int64_t)H * W * ops <= INT32_MAX)
+        return launch_lds8x16_warp(prv, nxt, flo, out, B, H, W, C, ops, slope, pad84, s);
     const int regs_x = (W + 7) / 8, regs_y = (H + 7) / 8;
     const int64_t nblk = (int64_t)regs_x * regs_y * B;
     if (nblk > INT32_MAX || (int64_t)(H + 8) * (W + 8) * C * 4 >= 0x7fffffff ||

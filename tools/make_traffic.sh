@@ -15,10 +15,10 @@ for cfg in 2 4 5; do
   python3 tools/traffic_from_pmc.py gpurun_out/pmc_cv84_c$cfg profiles/traffic.json "$tag" \
       ${pre}cost_volume_L4_bytes_per_launch="${cv}<false>" \
       ${pre}warp_clamp_L4_bytes_per_launch=warp_nhwc \
-      ${pre}warp_cost_volume_L4_bytes_per_launch="${cv}<true>" || true
+      ${pre}warp_cost_volume_L4_bytes_per_launch="${cv}<true>|lds8x16_warp_kernel|lds16_kernel<true>" || true
   sfx=""; [ "$cfg" = 2 ] || sfx="_c$cfg"
   python3 tools/pmc_summary.py gpurun_out/pmc_cv84_c$cfg "kernel<false>" > profiles/${tag}_pmc_cost_volume_L4$sfx.txt
-  python3 tools/pmc_summary.py gpurun_out/pmc_cv84_c$cfg "kernel<true>" > profiles/${tag}_pmc_warp_cost_volume_L4$sfx.txt
+  python3 tools/pmc_summary.py gpurun_out/pmc_cv84_c$cfg "kernel<true>|lds8x16_warp_kernel" > profiles/${tag}_pmc_warp_cost_volume_L4$sfx.txt
   python3 tools/pmc_summary.py gpurun_out/pmc_cv84_c$cfg warp_nhwc > profiles/${tag}_pmc_warp_L4$sfx.txt
 done
 cp profiles/traffic.json gpurun_out/traffic.json

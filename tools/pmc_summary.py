@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if filt and filt not in k:
+        if filt and not any(a in k for a in filt.split("|")):
             continue
         a = acc[k[:70]][r["Counter_Name"]]
         a[0] += 1

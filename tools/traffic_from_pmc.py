@@ -7,7 +7,7 @@ exactly half of the bytes of a wide (16 B/lane) coalesced streaming read -> doub
 streaming stores.  The file is stamped with the sha256 of the kernel sources (qpwcnet_amd._hip.source_sha256):
 bench.py drops `roofline.traffic` when the sources have changed since.
 
-usage: traffic_from_pmc.py <pmc dir> <out.json> <tag> <key>=<kernel substring> [...]
+usage: traffic_from_pmc.py <pmc dir> <out.json> <tag> <key>=<kernel substring>[|<alternative>...] [...]
 An existing <out.json> with the same source hash and tag is extended (one call per profiled shape)."""
 import csv
 import glob
@@ -40,7 +40,7 @@ d.update({k: v for k, v in prev.items() if k not in d})
 for key, sub in pairs:
     vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
     for r in rows:
-        if sub in r["Kernel_Name"] and r["Counter_Name"] in vals:
+        if any(a in r["Kernel_Name"] for a in sub.split("|")) and r["Counter_Name"] in vals:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     if not vals["FETCH_SIZE"] or not vals["WRITE_SIZE"]:
         print("no counters for", key, sub)
