@@ -506,7 +506,8 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
                             baseline_config_name(B, hw, dtype, world), B, hw[0], hw[1],
                             "fp32" if dtype == "f32" else "fp16 storage (fp32 accumulate)", args.data_format),
             "global_batch": world * B, "batch_per_gpu": B,
-            "parallelism": "dp{} (pairs sharded, RCCL all-gather of the 6 per-level EPE)".format(world),
+            "parallelism": "dp{} (pairs sharded, {} all-gather of the 6 per-level EPE)".format(
+                world, "gloo REHEARSAL on one GPU:" if gloo else "RCCL"),
             "hipgraph": graphs is not None,
             "epe_payload": ("written by the captured EPE reduction (two graphs over one memory pool, replayed "
                             "alternately; no per-step copy)" if graphs is not None and in_place else "copied per step"),

@@ -203,6 +203,43 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kOob = 0x80000000u;  // >= any descriptor size we accept: the load returns 0
 
+// WarpV2's clamp-mode blend (common.h: blend<QPWC_WARP_CLAMP>) on two channels at a time: the same three lerps, every
+// subtract / multiply / add rounded separately (contraction off), as packed fp32 instructions (v_pk_add_f32 /
+// v_pk_mul_f32) -- bit-identical to the scalar form, half the vector-ALU issue slots of the gather.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 blend_clamp2(float ax, float ay, f32x2 tl, f32x2 tr, f32x2 bl, f32x2 br) {
+#pragma clang fp contract(off)
+    const f32x2 top = ax * (tr - tl) + tl;
+    const f32x2 bot = ax * (br - bl) + bl;
+    return ay * (bot - top) + top;
+}
+#ifndef QPWC_PK_BLEND
+#define QPWC_PK_BLEND 0   // 1 = packed fp32 blend: bit-identical, measured +-0 (B=8 L4 47.5 vs 47.5-47.9 us), so the scalar code of common.h stays
+#endif
+__device__ __forceinline__ u32x4 blend_clamp_chunk(float ax, float ay, u32x4 tl, u32x4 tr, u32x4 bl, u32x4 br) {
+    u32x4 v;
+    if (!QPWC_PK_BLEND) {
+        Taps t;
+        t.ax = ax;
+        t.ay = ay;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = __float_as_uint(blend<QPWC_WARP_CLAMP>(t, __uint_as_float(tl[e]), __uint_as_float(tr[e]),
+                                                          __uint_as_float(bl[e]), __uint_as_float(br[e])));
+        return v;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const f32x2 r = blend_clamp2(ax, ay, f32x2{__uint_as_float(tl[e]), __uint_as_float(tl[e + 1])},
+                                     f32x2{__uint_as_float(tr[e]), __uint_as_float(tr[e + 1])},
+                                     f32x2{__uint_as_float(bl[e]), __uint_as_float(bl[e + 1])},
+                                     f32x2{__uint_as_float(br[e]), __uint_as_float(br[e + 1])});
+        v[e] = __float_as_uint(r.x);
+        v[e + 1] = __float_as_uint(r.y);
+    }
+    return v;
+}
+
 // Region order of the workgroup-shared kernels: column STRIPS of 128 pixels, row-major inside a strip.  An XCD takes a
 // contiguous run of this order (xcd_swizzle) and has ~100 regions in flight: in plain row-major order over a 1024-pixel
 // wide level (BASELINE config 4) that is one whole row of regions, whose 16-row neighbourhood plus the 84-float
@@ -1034,16 +1071,7 @@ __global__ __launch_bounds__(512, 2) void cost_volume_mfma_lds8x16_warp_kernel(
             c[q][3] = __builtin_amdgcn_raw_buffer_load_b128(rn, o, soff + (int)(rowb + pixb), 0);
         };
         auto mix = [&](int q) __attribute__((always_inline)) {
-            Taps t;
-            t.ax = ax[q];
-            t.ay = ay[q];
-            u32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[e] = __float_as_uint(blend<QPWC_WARP_CLAMP>(
-                    t, __uint_as_float(c[q][0][e]), __uint_as_float(c[q][1][e]), __uint_as_float(c[q][2][e]),
-                    __uint_as_float(c[q][3][e])));
-            return v;
+            return blend_clamp_chunk(ax[q], ay[q], c[q][0], c[q][1], c[q][2], c[q][3]);
         };
 #pragma unroll
         for (int q = 0; q < PR; ++q) issue(q, q);
