@@ -100,6 +100,9 @@ class QpwcNet:
         self.batch_frames = bool(batch_frames)
         self.overlap_streams = bool(overlap_streams)
         self._side = None
+        self._sides = []
+        # side stream of each decoder level in the two-stream forward (see _forward_two_streams)
+        self.dec_stream_of = (0, 0, 0, 0)
         # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
         self.dec_chunks = (2, 4, 4, 4)
         # launch order of flow levels (F) and decoder levels (D) in the two-stream forward, see _forward_two_streams
@@ -211,8 +214,20 @@ class QpwcNet:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=encs[-1].device)
-        side = self._side
-        side.wait_stream(main)              # encoder outputs are ready
+        # decoder level i runs on side stream dec_stream_of[i] (default: one side stream for the whole decoder).
+        # Round 3, tools/dec_streams_ab.py (one mapping per process): (0,1,1,1) 1.216 vs 1.221 ms/step, (0,1,2,2) 1.223,
+        # (0,1,2,3) 1.223 -- level 1's late release (see below) does not come from what is queued behind decoder level
+        # 0 on ITS stream; a mapping that RETURNS to an earlier stream, e.g. (0,1,0,1), makes two side streams wait on
+        # each other alternately and the runtime dies with SIGSEGV while capturing / instantiating the graph -- the
+        # round-1 "four staggered streams" crash.  Unsupported by this build: refused here.
+        if any(b < a for a, b in zip(self.dec_stream_of, self.dec_stream_of[1:])) or min(self.dec_stream_of) < 0:
+            raise ValueError("dec_stream_of must be non-decreasing side-stream indices, got {}".format(self.dec_stream_of))
+        n_side = max(self.dec_stream_of) + 1
+        while len(self._sides) < n_side:
+            self._sides.append(self._side if not self._sides else torch.cuda.Stream(device=encs[-1].device))
+        sides = self._sides[:n_side]
+        for sd in sides:
+            sd.wait_stream(main)            # encoder outputs are ready
         # One library launch over the 2B stacked frames fills the chip with long-lived workgroups and the small
         # critical-path kernels beside it wait for CUs; two launches of B frames each leave room for them
         # (B=8: 1.343 -> 1.309 ms/step; 4 chunks: no further gain; B=32: the launches are multi-round anyway, -1 %)
@@ -239,6 +254,9 @@ class QpwcNet:
         for tok in order:
             i = int(tok[1:])
             if tok[0] == "D":
+                side = sides[self.dec_stream_of[i]]
+                if i > 0 and self.dec_stream_of[i - 1] != self.dec_stream_of[i]:
+                    side.wait_event(ready[i - 1])       # the previous decoder level ran on another side stream
                 with torch.cuda.stream(side):
                     hip_chunks = self.dec_chunks[i] if small else 1
                     f = self.dec[i].cat_skip(f, encs[k], batch_chunks=chunks, hip_chunks=hip_chunks)
@@ -247,6 +265,9 @@ class QpwcNet:
                     # is not handed to a later side-stream allocation while main may still be reading it (the
                     # join at the end orders main after side, not side's NEXT use after main's reads)
                     f.record_stream(main)
+                    for sd in sides:
+                        if sd is not side:
+                            f.record_stream(sd)
                     decs[i] = f
                     ready[i] = torch.cuda.Event()
                     ready[i].record(side)
@@ -259,7 +280,8 @@ class QpwcNet:
                 flo = self.upflows[i - 1]((decs[i - 1][:nb], decs[i - 1][nb:], flo_u))
                 flos.append(flo)
         flos.append(self._up(flo, last=True))
-        main.wait_stream(side)              # join before anything is freed or returned
+        for sd in sides:
+            main.wait_stream(sd)            # join before anything is freed or returned
         return flos if self.train else flos[-1]
 
     @torch.no_grad()

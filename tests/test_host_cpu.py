@@ -350,3 +350,21 @@ def test_bench_line_fits_the_drivers_window():
     for v in ("533.5524", "18117.76", '"extra_configs"', '"whole_step"'):
         assert v in tail
     assert tail.count('"ms_per_step"') >= 2 and tail.count('"roofline"') >= 2
+
+
+def test_decoder_side_stream_mapping_must_not_return_to_an_earlier_stream():
+    """Round 3: a two-stream forward whose decoder levels alternate between two side streams makes the runtime crash
+    during hipGraph capture (the round-1 multi-stream crash, reproduced once in its own process by
+    tools/dec_streams_ab.py); the model refuses the mapping before any stream is touched."""
+    import numpy as np
+    from qpwcnet_amd.pwcnet import QpwcNet
+
+    class Enc:   # stands in for the stacked encoder outputs: only .shape / .device are read before the check
+        shape = (16, 8, 16, 256)
+        device = torch.device("cpu")
+    m = QpwcNet.__new__(QpwcNet)
+    m._side, m._sides, m.dec_stream_of = object(), [], (0, 1, 0, 1)
+    import unittest.mock as mock
+    with mock.patch("torch.cuda.current_stream", return_value=None):
+        with pytest.raises(ValueError, match="non-decreasing"):
+            m._forward_two_streams([Enc()], 8)
