@@ -87,7 +87,6 @@ class EpeGather:
         self.L = int(n_levels)
         self.pending = []
         self.slot = 0
-        self._copy_stream = None
         w = self.L + 1
         self.payload = [torch.zeros(w, dtype=dtype, device=device) for _ in range(2)]
         for p in self.payload:
@@ -115,28 +114,9 @@ class EpeGather:
                 raise RuntimeError("EpeGather: slot {} submitted, slot {} is next".format(slot, k))
         self.slot ^= 1
         if not self.collective:
-            # single process: nothing to exchange.  A slot result lives in a payload window that comes round again
-            # two steps later, so it is copied out -- on a side stream, ordered after the producer by an event, the
-            # way the collective runs on RCCL's own stream: the copy (a 4.6 us launch when it sat at the head of the
-            # next forward) overlaps the next step and collect() makes the caller's stream wait for it one step later.
-            if slot is None:
-                self.pending.append((None, local_epe.clone()))
-                return
-            src = self.payload[k][:self.L]
-            if src.is_cuda:
-                if self._copy_stream is None:
-                    self._copy_stream = torch.cuda.Stream(device=src.device)
-                produced = torch.cuda.Event()
-                produced.record(torch.cuda.current_stream(src.device))
-                with torch.cuda.stream(self._copy_stream):
-                    self._copy_stream.wait_event(produced)
-                    out = src.clone()
-                    done = torch.cuda.Event()
-                    done.record(self._copy_stream)
-                out.record_stream(torch.cuda.current_stream(src.device))
-                self.pending.append((done, out))
-            else:
-                self.pending.append((None, src.clone()))
+            # single process: nothing to exchange.  A slot result is the payload window itself until collect()
+            # clones it (the slot comes round again two steps later); a vector is kept as a clone.
+            self.pending.append((None, self.payload[k][:self.L] if slot is not None else local_epe.clone()))
             return
         if slot is None:
             self.payload[k][:self.L].copy_(local_epe)
@@ -148,8 +128,13 @@ class EpeGather:
             raise RuntimeError("EpeGather: nothing submitted")
         work, buf = self.pending.pop(0)
         if not self.collective:
-            if work is not None:     # the side-stream copy of a slot result (see submit)
-                torch.cuda.current_stream(buf.device).wait_event(work)
+            # a slot result is a window of the payload buffer that comes round again two steps later: hand out a
+            # copy, so that a caller who keeps the history (timed_steps' `results`) keeps every step's values.
+            # On the GPU that is one small launch per step on the compute stream (+6 us per 1.23 ms step; tools/
+            # epe_copy_ab.py, one process: 1.237 vs 1.230 ms without it; the same copy on a side stream ordered by
+            # events: 1.260 -- cross-stream events between graph replays cost more than the launch) -- the N > 1 path
+            # pays the same per-step clone after its all-gather.
+            buf = buf.clone()
             return buf.unsqueeze(0), buf
         work.wait()
         out = buf.view(self.world, self.L + 1)
