@@ -79,7 +79,14 @@ class EpeGather:
     ``collect()`` of step k made the caller's stream wait for all-gather k, which read it (at most two
     collectives are ever outstanding, enforced below)."""
 
-    def __init__(self, n_levels, device, n_local=1, dtype=torch.float32):
+    def __init__(self, n_levels, device, n_local=1, dtype=torch.float32, keep_history=None):
+        """keep_history: does collect() hand out a copy that stays valid for ever (True), or -- single process, vector
+        written in place -- the payload window itself, valid until its slot comes round again two steps later
+        (False)?  Default: copies wherever they cost nothing extra (a process group clones after its all-gather
+        anyway; CPU tensors), windows for a single process on a GPU, where the copy is one more launch per step on
+        the compute stream (tools/epe_copy_ab.py, one process: 1.237 vs 1.230 ms/step; on a side stream ordered by
+        events 1.260).  timed_steps() then returns None for the entries that are no longer valid instead of
+        aliases of two buffers."""
         # a process group of one rank still runs the collective (that is how the RCCL path is tested on
         # a one-GPU box); no process group = plain single process
         self.collective = dist.is_available() and dist.is_initialized()
@@ -87,6 +94,9 @@ class EpeGather:
         self.L = int(n_levels)
         self.pending = []
         self.slot = 0
+        if keep_history is None:
+            keep_history = self.collective or torch.device(device).type != "cuda"
+        self.keep_history = bool(keep_history) or self.collective
         w = self.L + 1
         self.payload = [torch.zeros(w, dtype=dtype, device=device) for _ in range(2)]
         for p in self.payload:
@@ -128,13 +138,9 @@ class EpeGather:
             raise RuntimeError("EpeGather: nothing submitted")
         work, buf = self.pending.pop(0)
         if not self.collective:
-            # a slot result is a window of the payload buffer that comes round again two steps later: hand out a
-            # copy, so that a caller who keeps the history (timed_steps' `results`) keeps every step's values.
-            # On the GPU that is one small launch per step on the compute stream (+6 us per 1.23 ms step; tools/
-            # epe_copy_ab.py, one process: 1.237 vs 1.230 ms without it; the same copy on a side stream ordered by
-            # events: 1.260 -- cross-stream events between graph replays cost more than the launch) -- the N > 1 path
-            # pays the same per-step clone after its all-gather.
-            buf = buf.clone()
+            # a slot result is a window of the payload buffer that comes round again two steps later
+            if self.keep_history:
+                buf = buf.clone()
             return buf.unsqueeze(0), buf
         work.wait()
         out = buf.view(self.world, self.L + 1)
@@ -154,7 +160,7 @@ def timed_steps(run_step, gather, steps, warmup, device, sync=None):
     payload) or the payload slot (int) it has already written in stream order.  Every step submits its
     all-gather and, once two are outstanding, collects the older one -- the exchange of step k travels
     while step k+1 computes.  -> (elapsed seconds, MAX over ranks; list of collected (per_rank, mean) in
-    step order for the timed steps)."""
+    step order for the timed steps -- None for steps whose result a history-less gather no longer holds)."""
     if sync is None:
         sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
 
@@ -188,6 +194,9 @@ def timed_steps(run_step, gather, steps, warmup, device, sync=None):
     barrier()
     sync()
     elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    if not getattr(gather, "keep_history", True):
+        # windows of two payload buffers: only the last two steps' results are still what they were
+        results = [None] * max(0, len(results) - 2) + results[-2:]
     return elapsed, results
 
 

@@ -192,10 +192,18 @@ def test_single_process_step_loop_keeps_every_steps_result():
         return s
 
     steps, warmup = 6, 2
+    assert gather.keep_history                                   # CPU tensors: copies cost nothing extra
     elapsed, results = qdist.timed_steps(run_step, gather, steps, warmup, "cpu")
     assert elapsed > 0 and len(results) == steps
     for i, (per_rank, mean) in enumerate(results):
         assert torch.equal(mean, base + 10.0 * (warmup + i)) and torch.equal(per_rank[0], mean)
+    # the history-less form (the default for a single process on a GPU: no extra launch per step): the entries that
+    # no longer hold their step's values come back as None, never as aliases of a later step
+    gather = qdist.EpeGather(6, "cpu", n_local=4, keep_history=False)
+    elapsed, results = qdist.timed_steps(run_step, gather, steps, warmup, "cpu")
+    assert len(results) == steps and results[:-2] == [None] * (steps - 2)
+    for i in (steps - 2, steps - 1):
+        assert torch.equal(results[i][1], base + 10.0 * (warmup + i))
 
 
 def test_bench_launches_itself_for_more_than_one_gpu():
