@@ -248,35 +248,45 @@ class QpwcNet:
         # Interleaving (F0 D0 F1 D1 F2 D2 F3 D3 F4) removes that wait and delays every later decoder level by
         # more: 1.253 vs 1.197-1.207 ms/step; five orders in between all land within 1 % of this one
         # (tools/capture_order_ab.py, one call; dropping the wait altogether -- a race -- would be worth 12-18 us).
+        # Round 3, "M<i>" = decoder level i on the caller's stream, one launch (tools/capture_order_ab.py main, one
+        # call, ms/step): default 1.2305; M0 F0 D1 D2 D3 F1.. 1.2290; M0 F0 D1 F1 D2 D3 F2.. 1.2237; F0 M0 D1.. 1.2608;
+        # M0 F0 M1 F1 D2.. 1.2527.  Kernel trace of the best one: level 1 then starts without a gap, but level 0 starts
+        # 31 us later (decoder level 0 in front of it) and level 2 takes 115 instead of 98 us beside decoder levels 2
+        # and 3 -- level 3 begins at 720 instead of 705 us of a forward either way.  The two chains of this phase
+        # (decoder levels 0-2: ~200 us alone; flow levels 0-2: ~200 us alone) share the chip for ~300 us whatever the
+        # order; the default order stays.
         order = self.capture_order
-        ready, decs, flos = {}, {}, []
+        ready, decs, flos, ran_on = {}, {}, [], {}
         f, k, flo = encs[-1], -2, None
         for tok in order:
             i = int(tok[1:])
-            if tok[0] == "D":
-                side = sides[self.dec_stream_of[i]]
-                if i > 0 and self.dec_stream_of[i - 1] != self.dec_stream_of[i]:
-                    side.wait_event(ready[i - 1])       # the previous decoder level ran on another side stream
+            if tok[0] in "DM":
+                # "D<i>": decoder level i on its side stream; "M<i>": on the caller's stream (one launch over the whole
+                # batch: a level the next flow level needs at once then costs no cross-queue wait)
+                side = main if tok[0] == "M" else sides[self.dec_stream_of[i]]
+                if i > 0 and ran_on[i - 1] is not side:
+                    side.wait_event(ready[i - 1])       # the previous decoder level ran on another stream
                 with torch.cuda.stream(side):
-                    hip_chunks = self.dec_chunks[i] if small else 1
-                    f = self.dec[i].cat_skip(f, encs[k], batch_chunks=chunks, hip_chunks=hip_chunks)
+                    hip_chunks = (self.dec_chunks[i] if small else 1) if tok[0] == "D" else 1
+                    f = self.dec[i].cat_skip(f, encs[k], batch_chunks=chunks if tok[0] == "D" else 1, hip_chunks=hip_chunks)
                     k -= 1
                     # allocated on `side`, read by UpFlow on `main`: tell the caching allocator, so that the block
                     # is not handed to a later side-stream allocation while main may still be reading it (the
                     # join at the end orders main after side, not side's NEXT use after main's reads)
-                    f.record_stream(main)
-                    for sd in sides:
+                    for sd in [main] + sides:
                         if sd is not side:
                             f.record_stream(sd)
                     decs[i] = f
                     ready[i] = torch.cuda.Event()
                     ready[i].record(side)
+                    ran_on[i] = side
             elif i == 0:
                 flo = self.flow((encs[-1][:nb], encs[-1][nb:]))
                 flos.append(flo)
             else:
                 flo_u = self._up(flo)
-                main.wait_event(ready[i - 1])
+                if ran_on[i - 1] is not main:
+                    main.wait_event(ready[i - 1])
                 flo = self.upflows[i - 1]((decs[i - 1][:nb], decs[i - 1][nb:], flo_u))
                 flos.append(flo)
         flos.append(self._up(flo, last=True))

@@ -21,6 +21,10 @@ model = build_flower(True, hw, "channels_last", weights=weights, device=dev)
 cands = ["F0 D0 D1 D2 D3 F1 F2 F3 F4", "F0 D0 F1 D1 D2 D3 F2 F3 F4", "F0 D0 D1 F1 D2 D3 F2 F3 F4",
          "F0 D0 D1 F1 D2 F2 D3 F3 F4", "D0 F0 D1 D2 D3 F1 F2 F3 F4", "F0 D0 F1 D1 F2 D2 F3 D3 F4",
          "F0 D0 D1 D2 F1 D3 F2 F3 F4"]
+if len(sys.argv) > 1 and sys.argv[1] == "main":
+    # round 3: "M<i>" = decoder level i on the caller's stream (no cross-queue wait for the flow level that needs it)
+    cands = ["F0 D0 D1 D2 D3 F1 F2 F3 F4", "M0 F0 D1 D2 D3 F1 F2 F3 F4", "F0 M0 D1 D2 D3 F1 F2 F3 F4",
+             "M0 F0 D1 F1 D2 D3 F2 F3 F4", "M0 F0 M1 F1 D2 D3 F2 F3 F4", "M0 D1 F0 D2 D3 F1 F2 F3 F4"]
 graphs = []
 ref = None
 for c in cands:
