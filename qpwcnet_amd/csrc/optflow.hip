@@ -328,10 +328,10 @@ __device__ long long g_sc_census[4096 * 6];   // per workgroup: start, staged0, 
 
 __device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int F, bool ACT, bool VEC, bool ACT_OUT>
+template <int F, bool ACT, bool VEC, bool ACT_OUT, bool RES = false>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     DwSrc src, const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y, int slices) {
+    float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y, int slices, int n_work) {
     QPWC_FLOW_CHAIN_PRIO();
     // F = output channels of THIS workgroup.  slices > 1 (coarse levels: few tiles, many 32-channel steps): the
     // layer's slices * F outputs are split over `slices` workgroups per tile -- each repeats the (cheap)
@@ -346,10 +346,23 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile = wg / slices, fslice = wg - tile * slices;   // the slices of a tile are neighbours (shared input)
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int X0 = tx * kScTW, Y0 = ty * kScTH;
+    // Work item v = (tile, output slice).  n_work == gridDim.x: one per workgroup (coarse levels, sliced launches).
+    // n_work > gridDim.x (round 3, the big levels): RESIDENT workgroups walk the items blockIdx.x, + gridDim.x, ... --
+    // the first staging request of the next tile is issued before this tile's last matrix step and its epilogue, so
+    // a tile's exposed first load and its store-bound end (phase stamps: 5-7 k and 9-12 k cycles of a 60 k-cycle
+    // workgroup) overlap the neighbour's.  b / X0 / Y0 are the tile being FETCHED, eb / eX0 / eY0 the one in the
+    // matrix cores.
+    int b, X0, Y0, fslice;
+    auto locate = [&](int v) __attribute__((always_inline)) {
+        const int wg = xcd_swizzle(v, n_work);
+        const int tile = wg / slices;                 // the slices of a tile are neighbours (shared input)
+        fslice = wg - tile * slices;
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        b = tile / (tiles_x * tiles_y);
+        X0 = tx * kScTW;
+        Y0 = ty * kScTH;
+    };
+    locate(blockIdx.x);
     const int n = lane & 15, g = lane >> 4;
     const int FT = F * slices;                    // output pixel stride
     pw += (int64_t)fslice * F * cpad;
@@ -388,13 +401,16 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     const int sps = VEC ? (tid >> 3) : (tid >> 5);
     constexpr int SPT = VEC ? 32 : 8;
     int goff[NST];       // pixel offset of halo pixel `it` inside image b (-1 = outside; H*W < 2^31)
+    auto set_goff = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < NST; ++it) {
-        const int hp = sps + SPT * it;
-        const int hy = hp / kScHW, hx = hp - hy * kScHW;
-        const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
-        goff[it] = (hp < kScNH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
-    }
+        for (int it = 0; it < NST; ++it) {
+            const int hp = sps + SPT * it;
+            const int hy = hp / kScHW, hx = hp - hy * kScHW;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            goff[it] = (hp < kScNH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+        }
+    };
+    set_goff();
     float4 st4[VEC ? NST : 1];
     float4 wreg0, wreg1, wreg2, wreg3;   // F/32 of them in use (kept out of an array: no LDS promotion)
     float dreg[2];
@@ -601,96 +617,137 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     //   B: staged                                 -> prefetch, pointwise(k) || depthwise(k+1)
     const int nsteps = cpad / kScKC;
     constexpr int kYs = kScTH * kScTW * kScKC;
+    constexpr bool EARLY_NEXT = F < 64;   // when the next tile's first request is issued (see the last matrix step)
     SC_STAMP();
     fetch_in(0);
     fetch_w(0);
-    commit_in(0);
-    __syncthreads();
-    SC_STAMP();
-    SC_CENSUS(1);
-    if (nsteps > 1) fetch_in(kScKC);
-    depthwise(y_s);
-    SC_STAMP();
-    for (int k = 0; k + 1 < nsteps; ++k) {
+    // resident form: the accumulators are zeroed right before a tile's first matrix step (one-shot form: once, at the
+    // top of the kernel, where the compiler sinks the zeros into the first matrix instructions)
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < NFT; ++i) acc[m][i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    };
+    // RES (resident workgroups) is compiled in only for F <= 32: the loop keeps ~50 more registers alive (next tile's
+    // staged inputs, loop invariants hoisted out of it), which the 64- and 128-output kernels do not have -- they
+    // spilled 19 / 58 registers with it -- and the narrow layers are the latency-bound ones (2.5 TB/s at L4) anyway.
+    int v = blockIdx.x;
+    do {
+        // (this tile's step-0 inputs and weights were requested by the prologue above / during the previous tile)
+        const int eb = b, eX0 = X0, eY0 = Y0;     // the tile whose outputs this iteration produces
+        const bool more = RES && v + (int)gridDim.x < n_work;
+        auto next_tile_request = [&]() __attribute__((always_inline)) {
+            // the staging registers are free from here to the end of the tile: request the next tile's first step
+            locate(v + (int)gridDim.x);
+            set_goff();
+            fetch_in(0);
+        };
+        commit_in(0);
+        __syncthreads();
+        SC_STAMP();
+        SC_CENSUS(1);
+        if (nsteps > 1) fetch_in(kScKC);
+        else if (more && EARLY_NEXT) next_tile_request();
+        depthwise(y_s);
+        SC_STAMP();
+        for (int k = 0; k + 1 < nsteps; ++k) {
+            __syncthreads();
+            SC_STAMP();
+            commit_w();
+            commit_in((k + 1) * kScKC);
+            __syncthreads();
+            SC_STAMP();
+            fetch_w((k + 1) * kScKC);
+            if (k + 2 < nsteps) fetch_in((k + 2) * kScKC);
+            else if (more && EARLY_NEXT) next_tile_request();
+            if (RES && k == 0) zero_acc();
+            pointwise(y_s + (k & 1) * kYs);
+            depthwise(y_s + ((k + 1) & 1) * kYs);
+            // issue order: every matrix instruction (32 cycles in its pipe) followed by its share of the
+            // ~40 LDS reads and ~120 vector instructions of the depthwise convolution
+            constexpr int kNM = 16 * NFT;
+#pragma unroll
+            for (int i = 0; i < kNM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, (40 + kNM - 1) / kNM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (120 + kNM - 1) / kNM, 0);
+            }
+            SC_STAMP();
+        }
         __syncthreads();
         SC_STAMP();
         commit_w();
-        commit_in((k + 1) * kScKC);
         __syncthreads();
         SC_STAMP();
-        fetch_w((k + 1) * kScKC);
-        if (k + 2 < nsteps) fetch_in((k + 2) * kScKC);
-        pointwise(y_s + (k & 1) * kYs);
-        depthwise(y_s + ((k + 1) & 1) * kYs);
-        // issue order: every matrix instruction (32 cycles in its pipe) followed by its share of the
-        // ~40 LDS reads and ~120 vector instructions of the depthwise convolution
-        constexpr int kNM = 16 * NFT;
+        SC_CENSUS(2);
+        asm volatile("; last step: matrix work, block of 16 outputs by block, each block's bias + Mish + stores behind it");
+        // The accumulators of output block ft are final after its 16 matrix instructions: its epilogue (bias,
+        // Mish, two 16-byte stores) issues in the matrix pipe's shadow of block ft + 1 instead of after all of
+        // them (phase stamps, F = 128: 4.7 k cycles of matrix work followed by 9-12 k cycles of epilogue).
+        if (RES && nsteps == 1) zero_acc();
+        {
+            const float* ys = y_s + ((nsteps - 1) & 1) * kYs;
+            f32x4v yv[2][2];
 #pragma unroll
-        for (int i = 0; i < kNM; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, (40 + kNM - 1) / kNM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (120 + kNM - 1) / kNM, 0);
-        }
-        SC_STAMP();
-    }
-    __syncthreads();
-    SC_STAMP();
-    commit_w();
-    __syncthreads();
-    SC_STAMP();
-    SC_CENSUS(2);
-    asm volatile("; last step: matrix work, block of 16 outputs by block, each block's bias + Mish + stores behind it");
-    // The accumulators of output block ft are final after its 16 matrix instructions: its epilogue (bias,
-    // Mish, two 16-byte stores) issues in the matrix pipe's shadow of block ft + 1 instead of after all of
-    // them (phase stamps, F = 128: 4.7 k cycles of matrix work followed by 9-12 k cycles of epilogue).
-    {
-        const float* ys = y_s + ((nsteps - 1) & 1) * kYs;
-        f32x4v yv[2][2];
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                yv[u][m] = *reinterpret_cast<const f32x4v*>(ys + (32 * wave + 16 * m + n) * kScKC + (((4 * u + g) ^ sw) << 2));
-        float* orow[2];
-        bool ook[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int pix = 32 * wave + 16 * m + n;
-            const int gy = Y0 + pix / kScTW, gx = X0 + pix % kScTW;
-            ook[m] = gy < H && gx < W;
-            orow[m] = out + ((int64_t)(b * H + gy) * W + gx) * FT + 4 * g;
-        }
-        auto epilogue = [&](int ft) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+                for (int m = 0; m < 2; ++m)
+                    yv[u][m] = *reinterpret_cast<const f32x4v*>(ys + (32 * wave + 16 * m + n) * kScKC + (((4 * u + g) ^ sw) << 2));
+            float* orow[2];
+            bool ook[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
-                                       acc[m][ft][3] + bv.w);
-                // the activation applied once per output element instead of once per (halo) load of the next layer
-                if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
-                if (ook[m]) *reinterpret_cast<float4*>(orow[m] + 16 * ft) = z;
+                const int pix = 32 * wave + 16 * m + n;
+                const int gy = eY0 + pix / kScTW, gx = eX0 + pix % kScTW;
+                ook[m] = gy < H && gx < W;
+                orow[m] = out + ((int64_t)(eb * H + gy) * W + gx) * FT + 4 * g;
             }
-        };
+            auto epilogue = [&](int ft) __attribute__((always_inline)) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
 #pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) {
-            f32x4v wv[2];
+                for (int m = 0; m < 2; ++m) {
+                    float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
+                                           acc[m][ft][3] + bv.w);
+                    // the activation applied once per output element instead of once per (halo) load of the next layer
+                    if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
+                    if (ook[m]) *reinterpret_cast<float4*>(orow[m] + 16 * ft) = z;
+                }
+            };
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                wv[u] = *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScKC + (((4 * u + g) ^ sw) << 2));
+            for (int ft = 0; ft < NFT; ++ft) {
+                f32x4v wv[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
+                    wv[u] = *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScKC + (((4 * u + g) ^ sw) << 2));
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t], yv[u][m][t], acc[m][ft], 0, 0, 0);
-            if (ft > 0) epilogue(ft - 1);
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t], yv[u][m][t], acc[m][ft], 0, 0, 0);
+                // F >= 64: the request for the next tile's first step goes out here, once the last block's matrix
+                // instructions are issued and the operand registers are dead (earlier, its 24 staging registers on
+                // top of the 64 accumulators and the operands spilled 54 / 16 registers at F = 128 / 64)
+                if (!EARLY_NEXT && ft == NFT - 1) {
+                    __builtin_amdgcn_sched_barrier(0);   // the scheduler must not hoist these loads above the matrix work
+                    if (more) next_tile_request();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ft > 0) epilogue(ft - 1);
+            }
+            SC_STAMP();
+            epilogue(NFT - 1);
         }
+        SC_CENSUS(3);
         SC_STAMP();
-        epilogue(NFT - 1);
-    }
-    SC_CENSUS(3);
-    SC_STAMP();
+        // the next tile's first weight slice (an L2 hit) is requested only now: held across the epilogue together
+        // with the staged inputs it cost 54 spilled registers at F = 128
+        if (more) fetch_w(0);
+        // (no barrier here: in_s / dw_s were last read before the two barriers around commit_w, and y_s / w_s are not
+        // written again before the barrier that follows the next tile's commit_in(0))
+    } while (RES && (v += (int)gridDim.x) < n_work);
 }
 
 #ifdef QPWC_SC_WS
@@ -1020,13 +1077,27 @@ int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64
     return check_launch("sepconv3x3_fused_f16_kernel");
 }
 
+#ifndef QPWC_SC_RESIDENT
+#define QPWC_SC_RESIDENT 512   // resident workgroups of the fp32 fused SeparableConv2D (0 = one workgroup per tile)
+#endif
 template <int F>
 static void sepconv_dispatch(const DwSrc& d, int act, bool vec, const float* dw, const float* pw,
                              const float* bias, float* out, int H, int W, int C, int cpad, int tiles_x,
                              int tiles_y, dim3 grid, int slices, hipStream_t s) {
-#define QPWC_SC_LAUNCH(ACT, VEC, AO)                                                                      \
-    hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, ACT, VEC, AO>), grid, dim3(256), 0, s, d, dw, pw, bias, \
-                       out, H, W, C, cpad, tiles_x, tiles_y, slices)
+    // round 3: where a launch would be several rounds of one-shot workgroups (the big levels), 512 RESIDENT workgroups
+    // (2 per CU, what the kernel's 79 KB of LDS and 248 registers allow) walk the tiles instead
+    const int n_work = (int)grid.x;
+    const bool resident = F <= 32 && QPWC_SC_RESIDENT > 0 && slices == 1 && n_work > QPWC_SC_RESIDENT;
+    if (resident) grid.x = QPWC_SC_RESIDENT;
+#define QPWC_SC_LAUNCH(ACT, VEC, AO)                                                                               \
+    do {                                                                                                           \
+        if (F <= 32 && resident)                                                                                   \
+            hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, ACT, VEC, AO, (F <= 32)>), grid, dim3(256), 0, s, d, dw, \
+                               pw, bias, out, H, W, C, cpad, tiles_x, tiles_y, slices, n_work);                    \
+        else                                                                                                       \
+            hipLaunchKernelGGL((sepconv3x3_fused_kernel<F, ACT, VEC, AO, false>), grid, dim3(256), 0, s, d, dw, pw, \
+                               bias, out, H, W, C, cpad, tiles_x, tiles_y, slices, n_work);                        \
+    } while (0)
     const bool in_act = (act & 1) != 0, out_act = (act & 2) != 0;   // QPWC_MISH_ON_LOAD / _ON_STORE
     if (out_act) {
         if (in_act) { if (vec) QPWC_SC_LAUNCH(true, true, true); else QPWC_SC_LAUNCH(true, false, true); }
