@@ -183,6 +183,26 @@ def test_sepconv3x3_fused(chans, F, hw, act):
     torch.testing.assert_close(out_act, torch_ref.mish(ref), rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("C,F", [(64, 32), (32, 16), (40, 16)])
+@pytest.mark.parametrize("act", [False, True])
+def test_sepconv3x3_fused_resident_workgroups(C, F, act):
+    """Round 3: launches of more than 512 tiles with F <= 32 run as 512 RESIDENT workgroups that walk the tiles and
+    request the next tile's first step early.  676 ragged tiles (100 x 200 pixels are 12.5 x 12.5
+    tiles), so workgroups own one or two tiles and the last tiles of a row / image are partial; against the oracle."""
+    rng = np.random.default_rng(C + F)
+    B, H, W = 4, 100, 200
+    assert B * ((H + 7) // 8) * ((W + 15) // 16) > 512
+    x = _rand(rng, B, H, W, C)
+    dw = _rand(rng, C, 1, 3, 3)
+    pw = _rand(rng, F, C, 1, 1) / np.sqrt(C)
+    bias = _rand(rng, F)
+    y = torch_ref.depthwise3x3([x], dw, act)
+    ref = torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw, bias).permute(0, 2, 3, 1)
+    out = ops.sepconv3x3([x.to(DEV)], dw.to(DEV), ops.pad_pointwise(pw.to(DEV)), bias.to(DEV), mish_on_load=act,
+                         mish_on_store=True).cpu()
+    torch.testing.assert_close(out, torch_ref.mish(ref), rtol=0, atol=5e-5)
+
+
 @pytest.mark.parametrize("tail,stride", [(1, 1), (1, 2), (2, 2), (3, 3), (3, 4), (1, 5)])
 def test_sepconv3x3_fused_short_tail_source(tail, stride):
     """The 16-byte path reads a short last source (1..3 channels) with a load that ENDS at its last channel;
