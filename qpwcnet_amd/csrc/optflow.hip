@@ -1077,6 +1077,9 @@ int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64
     return check_launch("sepconv3x3_fused_f16_kernel");
 }
 
+#ifndef QPWC_SC_SLICE_TARGET
+#define QPWC_SC_SLICE_TARGET 192   // split a layer's outputs over workgroups until the launch has this many
+#endif
 #ifndef QPWC_SC_RESIDENT
 #define QPWC_SC_RESIDENT 512   // resident workgroups of the fp32 fused SeparableConv2D (0 = one workgroup per tile)
 #endif
@@ -1130,7 +1133,7 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
     // few tiles (coarse pyramid levels): split the outputs over 2 / 4 / 8 workgroups per tile (slices of >= 16
     // outputs) until the launch has ~one workgroup per CU
     int slices = 1;
-    while (nblk * slices < 192 && F / (slices * 2) >= 16) slices *= 2;
+    while (nblk * slices < QPWC_SC_SLICE_TARGET && F / (slices * 2) >= 16) slices *= 2;
     const dim3 grid((unsigned)(nblk * slices));
     // 16-byte loads: every source but the last holds a multiple of 4 channels in 16-byte aligned
     // pixels; the last one either does too or is read element-wise (it must not straddle a quad
