@@ -328,11 +328,21 @@ __device__ long long g_sc_census[4096 * 6];   // per workgroup: start, staged0, 
 
 __device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifndef QPWC_SC_ASYM_PRIO
+#define QPWC_SC_ASYM_PRIO 0   // A/B: asymmetric wave priority inside the fused SeparableConv2D (see the kernel)
+#endif
 template <int F, bool ACT, bool VEC, bool ACT_OUT, bool RES = false>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
     DwSrc src, const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y, int slices, int n_work) {
     QPWC_FLOW_CHAIN_PRIO();
+#if QPWC_SC_ASYM_PRIO
+    // Two waves share a SIMD (one of each resident workgroup).  When both are in their matrix phase each runs at half
+    // rate and they leave it together -- a stable lock step in which the matrix pipe idles while both do their
+    // staging / depthwise / store work.  The wave in the odd hardware slot asks for more issue priority: it finishes its
+    // matrix phase at full rate while the other waits, and from then on the two alternate.
+    if (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_setprio(3);   // HW_ID.wave_id bit 0
+#endif
     // F = output channels of THIS workgroup.  slices > 1 (coarse levels: few tiles, many 32-channel steps): the
     // layer's slices * F outputs are split over `slices` workgroups per tile -- each repeats the (cheap)
     // depthwise convolution and takes 1 / slices of the matrix work, and the launch has slices x more
