@@ -23,7 +23,10 @@ gt_pyr = metrics.multiscale_ground_truth(torch.from_numpy(gt_np).to(dev), [(hw[0
 model = build_flower(True, hw, "channels_last", weights=weights, device=dev)
 for a in sys.argv[1:]:
     k, v = a.split("=", 1)
-    setattr(model, k, ast.literal_eval(v))
+    if "." in k or "[" in k:      # a dotted path below the model, e.g. "upflows[0].flow.fused_sepconv=True"
+        exec("model.{} = ast.literal_eval(v)".format(k))
+    else:
+        setattr(model, k, ast.literal_eval(v))
 g = GraphedForward(model, pairs, epilogue=lambda fl: metrics.per_level_epe(gt_pyr, fl), warmup=2)
 ts = []
 for _ in range(6):
