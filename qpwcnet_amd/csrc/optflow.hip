@@ -1529,6 +1529,7 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
     __shared__ __attribute__((aligned(16))) float w3_s[32 * 32];
     __shared__ __attribute__((aligned(16))) float w4_s[16 * 32];
     __shared__ __attribute__((aligned(16))) float dw_s[9 * 32];
+    __shared__ __attribute__((aligned(16))) float wf_s[9 * 32];                 // taps of the final 3 x 3 convolution
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, n = lane & 15, g = lane >> 4, sw = n >> 1;
@@ -1538,12 +1539,56 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
     const float* zb = z2 + (int64_t)b * H * W * 64;
     const int cq = tid & 7, pr = tid >> 3;      // depthwise map: channel quad, pixel row of 32
 
+    // Round 3: EVERY global load of the workgroup is issued here, before the first barrier -- both 32-channel steps of
+    // the input tile, both weight slices, all depthwise taps, biases, flow-head parameters.  The kernel used to pay one
+    // exposed L2 / HBM round trip per phase (step 0, step 1, layer-4 taps, head parameters, the 18 tap loads of the final
+    // 3 x 3 convolution): five to six of them in a 17 us workgroup whose arithmetic is a few us.
+    // (wr as an array of two was not promoted to registers: it went to scratch memory behind an s_waitcnt vmcnt(0),
+    // which undid the prefetch -- two named variables instead)
+    float4 st[2][7], wr0, wr1;
+    float dr[2][2], dr4[2];
+    auto request_step = [&](auto step_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(step_c)::value;
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx >> 3, q = idx & 7;
+            const int gy = Y0 - 3 + hp / kTlR2, gx = X0 - 3 + hp % kTlR2;
+            st[s][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < kTlN2 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                st[s][it] = *reinterpret_cast<const float4*>(zb + ((int64_t)gy * W + gx) * 64 + 32 * s + 4 * q);
+        }
+        (s ? wr1 : wr0) = *reinterpret_cast<const float4*>(pw3 + (tid >> 3) * 64 + 32 * s + 4 * (tid & 7));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            dr[s][i] = idx < 288 ? dw3[32 * s * 9 + idx] : 0.0f;
+        }
+    };
+    request_step(std::integral_constant<int, 0>{});
+    request_step(std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        dr4[i] = idx < 288 ? dw4[idx] : 0.0f;
+    }
     // pointwise 32 -> 16 weights: 16 rows x 8 chunks, chunk q of row f at q ^ ((f & 15) >> 1)
     if (tid < 128) {
         const int f = tid >> 3, q = tid & 7;
         *reinterpret_cast<float4*>(w4_s + f * 32 + ((q ^ ((f & 15) >> 1)) << 2)) =
             *reinterpret_cast<const float4*>(pw4 + f * 32 + 4 * q);
     }
+    // the 3 x 3 x 16 x 2 taps of the final convolution (head + 304 ...): 288 floats
+    if (tid < 72) *reinterpret_cast<float4*>(wf_s + 4 * tid) = *reinterpret_cast<const float4*>(head + 304 + 4 * tid);
+    // flow-head parameters (as flow_head_kernel): w1[16][16] | b1 | bn_scale | bn_shift | wf[3][3][16][2]
+    const f32x4v w1v = *reinterpret_cast<const f32x4v*>(head + n * 16 + 4 * g);
+    const float4 b1v = *reinterpret_cast<const float4*>(head + 256 + 4 * g);
+    const float4 bsv = *reinterpret_cast<const float4*>(head + 272 + 4 * g);
+    const float4 btv = *reinterpret_cast<const float4*>(head + 288 + 4 * g);
+    const float4 b4v = *reinterpret_cast<const float4*>(b4 + 4 * g);
+    float4 b3v[2];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) b3v[ft] = *reinterpret_cast<const float4*>(b3 + 16 * ft + 4 * g);
 
     // ================= phase A: z3 = Mish(pointwise3(depthwise3(z2)) + b3) on the 12 x 12 region ==============
     f32x4v acc3[3][2];
@@ -1551,45 +1596,29 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) acc3[i][ft] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int s = 0; s < 2; ++s) {
+    // one 32-channel step of phase A; the step index is a compile-time constant so that st / wr / dr stay in registers
+    auto phase_a_step = [&](auto step_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(step_c)::value;
         if (s) __syncthreads();   // the previous step's operand reads are done
         // ---- stage the 14 x 14 x 32 input tile, the 32 x 32 weight slice and the 32 x 9 depthwise taps ----
-        float4 st[7];
-#pragma unroll
-        for (int it = 0; it < 7; ++it) {
-            const int idx = tid + 256 * it;
-            const int hp = idx >> 3, q = idx & 7;
-            const int gy = Y0 - 3 + hp / kTlR2, gx = X0 - 3 + hp % kTlR2;
-            st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hp < kTlN2 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                st[it] = *reinterpret_cast<const float4*>(zb + ((int64_t)gy * W + gx) * 64 + 32 * s + 4 * q);
-        }
-        const float4 wr = *reinterpret_cast<const float4*>(pw3 + (tid >> 3) * 64 + 32 * s + 4 * (tid & 7));
-        float dr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            dr[i] = idx < 288 ? dw3[32 * s * 9 + idx] : 0.0f;
-        }
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
             const int idx = tid + 256 * it;
             const int hp = idx >> 3, q = idx & 7;
             if (hp < kTlN2) {
-                float4 v = st[it];
+                float4 v = st[s][it];
                 if (ACT_IN) v = make_float4(mishf(v.x), mishf(v.y), mishf(v.z), mishf(v.w));   // mish(0) == 0
                 *reinterpret_cast<float4*>(in_s + hp * kTlPS + 4 * q) = v;
             }
         }
         {
             const int f = tid >> 3, q = tid & 7;
-            *reinterpret_cast<float4*>(w3_s + f * 32 + ((q ^ ((f & 15) >> 1)) << 2)) = wr;
+            *reinterpret_cast<float4*>(w3_s + f * 32 + ((q ^ ((f & 15) >> 1)) << 2)) = s ? wr1 : wr0;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < 288) dw_s[(idx % 9) * 32 + idx / 9] = dr[i];
+            if (idx < 288) dw_s[(idx % 9) * 32 + idx / 9] = dr[s][i];
         }
         __syncthreads();
         // ---- depthwise 3x3 on the 12 x 12 region: thread = channel quad cq, pixels pr + 32 j ----
@@ -1637,7 +1666,9 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
                 }
             }
         }
-    }
+    };
+    phase_a_step(std::integral_constant<int, 0>{});
+    phase_a_step(std::integral_constant<int, 1>{});
     // ---- z3 = Mish(acc + b3), zero outside the image, to LDS (pixel stride 40) ----
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1648,7 +1679,7 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
             const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
-                const float4 bv = *reinterpret_cast<const float4*>(b3 + 16 * ft + 4 * g);
+                const float4 bv = b3v[ft];
                 float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (in) z = make_float4(mishf(acc3[i][ft][0] + bv.x), mishf(acc3[i][ft][1] + bv.y),
                                         mishf(acc3[i][ft][2] + bv.z), mishf(acc3[i][ft][3] + bv.w));
@@ -1656,19 +1687,13 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
             }
         }
     }
-    // depthwise taps of layer 4
+    // depthwise taps of layer 4 (loaded at the top of the kernel)
     {
-        float dr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            dr[i] = idx < 288 ? dw4[idx] : 0.0f;
-        }
         __syncthreads();   // z3 complete; y3 / w3 / dw_s / in_s free
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < 288) dw_s[(idx % 9) * 32 + idx / 9] = dr[i];
+            if (idx < 288) dw_s[(idx % 9) * 32 + idx / 9] = dr4[i];
         }
     }
     __syncthreads();
@@ -1702,12 +1727,7 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
     __syncthreads();
     float* h_s = y3_s;    // [112][16]
     {
-        // flow-head parameters (as flow_head_kernel): w1[16][16] | b1 | bn_scale | bn_shift | wf[3][3][16][2]
-        const f32x4v w1v = *reinterpret_cast<const f32x4v*>(head + n * 16 + 4 * g);
-        const float4 b1v = *reinterpret_cast<const float4*>(head + 256 + 4 * g);
-        const float4 bsv = *reinterpret_cast<const float4*>(head + 272 + 4 * g);
-        const float4 btv = *reinterpret_cast<const float4*>(head + 288 + 4 * g);
-        const float4 b4v = *reinterpret_cast<const float4*>(b4 + 4 * g);
+        // (flow-head parameters w1v / b1v / bsv / btv / b4v: loaded at the top of the kernel)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int grp = wave + 4 * i;
@@ -1742,7 +1762,7 @@ __global__ __launch_bounds__(256, 2) void optflow_tail_kernel(
     __syncthreads();
     // ================= phase D: flow = scale * conv3x3(h), 16 -> 2; wave w = tile rows 2 w, 2 w + 1 ==========
     {
-        const float* wf = head + 304;
+        const float* wf = wf_s;   // staged at the top of the kernel
         const int p = 16 * wave + n, r = p >> 3, c = p & 7;
         float fx = 0.0f, fy = 0.0f;
 #pragma unroll
