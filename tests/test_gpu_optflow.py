@@ -159,7 +159,10 @@ def test_cost_volume_fp16_matrix_core_kernel(shape):
 
 
 @pytest.mark.parametrize("chans,F", [((81, 32, 2), 128), ((81, 256, 256), 128), ((128,), 64), ((64,), 32),
-                                     ((32,), 16), ((7, 3), 16)])
+                                     ((32,), 16), ((7, 3), 16),
+                                     # three steps and more on the narrow kernels (two staging sets, round 3):
+                                     # 3 / 4 / 5 steps, and a 3-source layer whose outputs are split over workgroups
+                                     ((96,), 32), ((128,), 32), ((160,), 16), ((84, 64, 2), 32)])
 @pytest.mark.parametrize("hw", [(8, 16), (19, 37)])
 @pytest.mark.parametrize("act", [False, True])
 def test_sepconv3x3_fused(chans, F, hw, act):
