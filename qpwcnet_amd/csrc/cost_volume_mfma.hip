@@ -990,6 +990,9 @@ __global__ __launch_bounds__(1024) void cost_volume_mfma_lds16_kernel(
 // each) and still stages every nxt pixel 3 x instead of 4 x (24 + 8 = 32 block loads per 8 tiles = 4 per tile).
 //   pieces : block B = it*4 + (wave >> 1), it = 0..7: blocks 0..23 = nxt (bi, bj) = (B / 6, B % 6) of the 16-row x
 //            24-column neighbourhood, 24..31 = prv tile B - 24; every lane stages 6 nxt + 2 prv pieces per step.
+#ifndef QPWC_R8_PR
+#define QPWC_R8_PR 3   // A/B: 6 = every gather of the first step in one round: 48.0-48.8 vs 47.3-47.8 us, not better
+#endif
 constexpr int kR8NxtBlocks = 24, kR8Blocks = 32;
 constexpr int kR8StageBytes = kR8Blocks * 2048;              // 65536
 constexpr int kR8FrameBytes = 8 * kFrameFloats * 4;          // 75776: the 10 KB past the staging image hold the records
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(512, 2) void cost_volume_mfma_lds8x16_warp_kernel(
     const int nsteps = C / 32;
     auto step = [&](int s, auto first) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value;
-        constexpr int PR = FIRST ? 3 : 2;            // pieces per round: no accumulator is live in the first step
+        constexpr int PR = FIRST ? QPWC_R8_PR : 2;   // pieces per round: no accumulator is live in the first step
         const int soff = s * 128;
         u32x4 c[PR][4];
         float ax[PR], ay[PR];
