@@ -776,10 +776,10 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 // as in the fp16 cost volume.  pw: (F, Cpad) fp16, Cpad = ceil(C/32)*32; dw, bias fp32.
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 
-template <int F, bool ACT, bool ACT_OUT, bool WIDE>
+template <int F, bool ACT, bool ACT_OUT, bool WIDE, bool RES = false>
 __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     DwSrc src, const float* __restrict__ dw, const __half* __restrict__ pw, const float* __restrict__ bias,
-    __half* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y) {
+    __half* __restrict__ out, int H, int W, int C, int cpad, int tiles_x, int tiles_y, int n_work) {
     constexpr int NFT = F / 16;
     // WIDE : one dense source, 4 lanes x 16 B (8 channels) per halo pixel, 64 halo pixels per trip
     // else : up to three sources (virtual concat), 8 lanes x 8 B (4 channels) per pixel, 32 per trip;
@@ -793,9 +793,17 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int X0 = tx * kScTW, Y0 = ty * kScTH;
+    // RES (round 3, as in the fp32 kernel): resident workgroups walk the tiles blockIdx.x, + gridDim.x, ... and request
+    // the next tile's first step before this tile's last matrix step; b / X0 / Y0 = the tile being FETCHED.
+    int b, X0, Y0;
+    auto locate = [&](int v) __attribute__((always_inline)) {
+        const int tile = xcd_swizzle(v, n_work);
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        b = tile / (tiles_x * tiles_y);
+        X0 = tx * kScTW;
+        Y0 = ty * kScTH;
+    };
+    locate(blockIdx.x);
     const int n = lane & 15, g = lane >> 4;
 
     f32x4v acc[2][NFT];
@@ -807,13 +815,16 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     const int sch = WIDE ? 8 * (tid & 3) : 4 * (tid & 7);
     const int sps = WIDE ? (tid >> 2) : (tid >> 3);
     int goff[NST];
+    auto set_goff = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < NST; ++it) {
-        const int hp = sps + SPT * it;
-        const int hy = hp / kScHW, hx = hp - hy * kScHW;
-        const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
-        goff[it] = (hp < kScNH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
-    }
+        for (int it = 0; it < NST; ++it) {
+            const int hp = sps + SPT * it;
+            const int hy = hp / kScHW, hx = hp - hy * kScHW;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            goff[it] = (hp < kScNH && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+        }
+    };
+    set_goff();
     uint4 st[WIDE ? NST : 1], wreg0, wreg1;
     uint2 st2[WIDE ? 1 : NST];
     float dreg[2];
@@ -976,42 +987,63 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
     //   A: y_s[k&1] complete, w_s and in_s free   -> commit weights(k), inputs(k+1)
     //   B: staged                                 -> prefetch, pointwise(k) || depthwise(k+1)
     const int nsteps = cpad / kScKC;
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < NFT; ++i) acc[m][i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    };
     fetch_in(0);
     fetch_w(0);
-    commit_in();
-    __syncthreads();
-    if (nsteps > 1) fetch_in(kScKC);
-    depthwise(y_s);
-    for (int k = 0; k + 1 < nsteps; ++k) {
-        __syncthreads();
-        commit_w();
+    int v = blockIdx.x;
+    do {
+        const int eb = b, eX0 = X0, eY0 = Y0;     // the tile whose outputs this iteration produces
+        const bool more = RES && v + (int)gridDim.x < n_work;
+        auto next_tile_request = [&]() __attribute__((always_inline)) {
+            locate(v + (int)gridDim.x);
+            set_goff();
+            fetch_in(0);
+        };
         commit_in();
         __syncthreads();
-        fetch_w((k + 1) * kScKC);
-        if (k + 2 < nsteps) fetch_in((k + 2) * kScKC);
-        pointwise(y_s + (k & 1) * kYh);
-        depthwise(y_s + ((k + 1) & 1) * kYh);
-    }
-    __syncthreads();
-    commit_w();
-    __syncthreads();
-    pointwise(y_s + ((nsteps - 1) & 1) * kYh);
+        if (nsteps > 1) fetch_in(kScKC);
+        else if (more) next_tile_request();
+        depthwise(y_s);
+        for (int k = 0; k + 1 < nsteps; ++k) {
+            __syncthreads();
+            commit_w();
+            commit_in();
+            __syncthreads();
+            fetch_w((k + 1) * kScKC);
+            if (k + 2 < nsteps) fetch_in((k + 2) * kScKC);
+            else if (more) next_tile_request();
+            if (RES && k == 0) zero_acc();
+            pointwise(y_s + (k & 1) * kYh);
+            depthwise(y_s + ((k + 1) & 1) * kYh);
+        }
+        __syncthreads();
+        commit_w();
+        __syncthreads();
+        if (RES && nsteps == 1) zero_acc();
+        pointwise(y_s + ((nsteps - 1) & 1) * kYh);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int pix = 32 * wave + 16 * m + n;
-        const int gy = Y0 + pix / kScTW, gx = X0 + pix % kScTW;
-        if (gy < H && gx < W) {
-            __half* o = out + ((int64_t)(b * H + gy) * W + gx) * F;
+        for (int m = 0; m < 2; ++m) {
+            const int pix = 32 * wave + 16 * m + n;
+            const int gy = eY0 + pix / kScTW, gx = eX0 + pix % kScTW;
+            if (gy < H && gx < W) {
+                __half* o = out + ((int64_t)(eb * H + gy) * W + gx) * F;
 #pragma unroll
-            for (int ft = 0; ft < NFT; ++ft) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
-                float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
-                                       acc[m][ft][3] + bv.w);
-                if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
-                st4(o + 16 * ft + 4 * g, z);
+                for (int ft = 0; ft < NFT; ++ft) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+                    float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
+                                           acc[m][ft][3] + bv.w);
+                    if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
+                    st4(o + 16 * ft + 4 * g, z);
+                }
             }
         }
-    }
+        if (more) fetch_w(0);
+    } while (RES && (v += (int)gridDim.x) < n_work);
 }
 
 #ifndef QPWC_SC16_STREAM
@@ -1021,13 +1053,33 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
 #include "experimental/sepconv_f16_stream.inc"
 #endif
 
+#ifndef QPWC_SC16_RESIDENT
+#define QPWC_SC16_RESIDENT 512   // resident workgroups of the fp16 fused SeparableConv2D (0 = one workgroup per tile)
+#endif
+#ifndef QPWC_SC16_RES_MAXF
+#define QPWC_SC16_RES_MAXF 32    // widest layer that takes the resident form.  tools/sep16bench.py, B=32, us, resident vs
+                                 // one workgroup per tile (A/B build, one call): L4 F=32 65.4 vs 75.2, F=16 32.1 vs 35.4; L3 18.6 vs
+                                 // 21.6, 10.5 vs 11.0 -- but F=64 170.8 vs 155.2 (172 registers: 2 instead of 3 waves per SIMD)
+                                 // and F=128 266.8 vs 247.8: the narrow layers only, as in fp32
+#endif
 template <int F>
 static void sepconv_f16_dispatch(const DwSrc& d, bool wide, int act, const float* dw, const __half* pw,
                                  const float* bias, __half* out, int H, int W, int C, int cpad, int tiles_x,
                                  int tiles_y, dim3 grid, hipStream_t s) {
-#define QPWC_SCH_LAUNCH(ACT, AO, WD)                                                                        \
-    hipLaunchKernelGGL((sepconv3x3_fused_f16_kernel<F, ACT, AO, WD>), grid, dim3(256), 0, s, d, dw, pw, bias, \
-                       out, H, W, C, cpad, tiles_x, tiles_y)
+    // round 3: launches of more than QPWC_SC16_RESIDENT tiles run as that many resident workgroups (2 per CU)
+    const int n_work = (int)grid.x;
+    const int n_res = (F <= 32 ? 3 : 2) * (QPWC_SC16_RESIDENT / 2);   // 3 / 2 workgroups per CU fit (168 / 230 registers)
+    const bool resident = QPWC_SC16_RESIDENT > 0 && F <= QPWC_SC16_RES_MAXF && n_work > n_res;
+    if (resident) grid.x = n_res;
+#define QPWC_SCH_LAUNCH(ACT, AO, WD)                                                                           \
+    do {                                                                                                       \
+        if (F <= QPWC_SC16_RES_MAXF && resident)                                                               \
+            hipLaunchKernelGGL((sepconv3x3_fused_f16_kernel<F, ACT, AO, WD, (F <= QPWC_SC16_RES_MAXF)>), grid,  \
+                               dim3(256), 0, s, d, dw, pw, bias, out, H, W, C, cpad, tiles_x, tiles_y, n_work); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((sepconv3x3_fused_f16_kernel<F, ACT, AO, WD, false>), grid, dim3(256), 0, s, d,  \
+                               dw, pw, bias, out, H, W, C, cpad, tiles_x, tiles_y, n_work);                    \
+    } while (0)
     const bool in_act = (act & 1) != 0, out_act = (act & 2) != 0;
     if (wide) {
         if (in_act) { if (out_act) QPWC_SCH_LAUNCH(true, true, true); else QPWC_SCH_LAUNCH(true, false, true); }
