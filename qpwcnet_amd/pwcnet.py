@@ -104,7 +104,11 @@ class QpwcNet:
         # side stream of each decoder level in the two-stream forward (see _forward_two_streams)
         self.dec_stream_of = (0, 0, 0, 0)
         # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
-        self.dec_chunks = (2, 4, 4, 4)
+        # round 3 (tools/step_time.py "dec_chunks=...", three interleaved runs each in one call, ms/step): (2,4,4,4)
+        # 1.2147, (2,4,4,2) 1.1996, (2,4,4,1) 1.1991, (2,4,2,2) 1.2005, (2,2,4,1) 1.2031, (2,4,8,8) 1.296: the finest
+        # decoder level runs beside flow level 3, whose kernels fill the chip themselves -- one efficient launch that is
+        # over sooner disturbs them less than four that trickle
+        self.dec_chunks = (2, 4, 4, 1)
         # launch order of flow levels (F) and decoder levels (D) in the two-stream forward, see _forward_two_streams
         self.capture_order = ("F0", "D0", "D1", "D2", "D3", "F1", "F2", "F3", "F4")
         self.input_shape = tuple(input_shape)

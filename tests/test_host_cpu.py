@@ -271,7 +271,7 @@ def test_model_layout_plan_without_a_device():
     from qpwcnet_amd.pwcnet import build_flower
     m = build_flower(True, (64, 128), "channels_first", weights=synth.make_weights(42, (64, 128)), device="cpu")
     assert m.data_format == "channels_first" and m._df == "channels_first"
-    assert m.capture_order == ("F0", "D0", "D1", "D2", "D3", "F1", "F2", "F3", "F4") and m.dec_chunks == (2, 4, 4, 4)
+    assert m.capture_order == ("F0", "D0", "D1", "D2", "D3", "F1", "F2", "F3", "F4") and m.dec_chunks == (2, 4, 4, 1)
     assert all(u.fused for u in build_flower(True, (64, 128), "channels_last", weights=synth.make_weights(42, (64, 128)),
                                              device="cpu").upflows)
     with pytest.raises(ValueError):
