@@ -79,6 +79,9 @@ int conv3x3s2_mish_f16_launch(const void* x, const void* weight, const void* bia
                               int CI, hipStream_t s);
 int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s);
+int conv3x3_mish_x3_launch(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int C,
+                           int pad_h, int pad_w, hipStream_t s);
+int split_bf16x3_launch(const void* src, void* out, int64_t n, hipStream_t s);
 int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s);
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
@@ -562,6 +565,28 @@ int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, v
     if (overlaps(out, (size_t)B * (H + pad_h) * (W + pad_w) * C * 4, x, (size_t)B * H * W * C * 4))
         return fail(QPWC_E_ALIAS, "out overlaps x");
     return conv3x3_mish_launch(x, weight, bias, out, B, H, W, C, pad_h, pad_w, (hipStream_t)stream);
+}
+
+int qpwc_conv3x3_mish_x3_fwd(const void* x, const void* weight3, const void* bias, void* out, int B, int H,
+                             int W, int C, int pad_h, int pad_w, void* stream) {
+    if (!x || !weight3 || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (C != 16 && C != 32 && C != 64 && C != 128 && C != 256)
+        return fail(QPWC_E_SHAPE, "C=%d not in {16,32,64,128,256}", C);
+    if (B <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || pad_h > 8 || pad_w > 8)
+        return fail(QPWC_E_SHAPE, "bad shape B=%d H=%d W=%d pad=%d,%d", B, H, W, pad_h, pad_w);
+    if ((uintptr_t)x % 16 || (uintptr_t)weight3 % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
+        return fail(QPWC_E_ALIGN, "x, weight3, bias, out must be 16-byte aligned");
+    if (overlaps(out, (size_t)B * (H + pad_h) * (W + pad_w) * C * 4, x, (size_t)B * H * W * C * 4))
+        return fail(QPWC_E_ALIAS, "out overlaps x");
+    return conv3x3_mish_x3_launch(x, weight3, bias, out, B, H, W, C, pad_h, pad_w, (hipStream_t)stream);
+}
+
+int qpwc_split_bf16x3_fwd(const void* src, void* out, long long n, void* stream) {
+    if (!src || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (n <= 0 || n > ((long long)1 << 40)) return fail(QPWC_E_SHAPE, "n=%lld out of range", n);
+    if ((uintptr_t)src % 4 || (uintptr_t)out % 2) return fail(QPWC_E_ALIGN, "src must be 4-byte, out 2-byte aligned");
+    if (overlaps(out, (size_t)n * 6, src, (size_t)n * 4)) return fail(QPWC_E_ALIAS, "out overlaps src");
+    return split_bf16x3_launch(src, out, (int64_t)n, (hipStream_t)stream);
 }
 
 int qpwc_conv3x3_mish_f16_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,

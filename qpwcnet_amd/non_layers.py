@@ -287,10 +287,15 @@ class DownConv(_Weighted):
         pad_ok = want_padded and _same_pad(h, 3, 2) == (0, 1) and _same_pad(w, 3, 2) == (0, 1)
         if self._hip_conv_ok(y):
             # narrow levels: conv + bias + Mish (+ the next level's 'SAME' padding) in one HIP launch each
-            taps = self._taps(y.dtype)
-            y1 = ops.conv3x3_mish(y.permute(0, 2, 3, 1), taps[0], self.p32("conv_aa.bias"))
             pad = 1 if pad_ok else 0
-            y2 = ops.conv3x3_mish(y1, taps[1], self.p32("conv_b.bias"), pad, pad)
+            if self.matmul == "bf16x3" and y.dtype == torch.float32:
+                taps = self._taps_x3()
+                y1 = ops.conv3x3_mish_x3(y.permute(0, 2, 3, 1), taps[0], self.p32("conv_aa.bias"))
+                y2 = ops.conv3x3_mish_x3(y1, taps[1], self.p32("conv_b.bias"), pad, pad)
+            else:
+                taps = self._taps(y.dtype)
+                y1 = ops.conv3x3_mish(y.permute(0, 2, 3, 1), taps[0], self.p32("conv_aa.bias"))
+                y2 = ops.conv3x3_mish(y1, taps[1], self.p32("conv_b.bias"), pad, pad)
             if pad_ok:
                 return y2[:, :h, :w, :], y2
             return y2, None
@@ -306,6 +311,9 @@ class DownConv(_Weighted):
     # own 3x3 + bias + Mish kernels (qpwc_conv3x3_mish_fwd: 16 / 32 channels with the weights in registers,
     # 64 / 128 / 256 with a wave per 16-output block) instead of library convolution + bias/Mish pass
     hip_conv = True
+    # fp32 products of those kernels: "f32" = the fp32 matrix instructions, "bf16x3" = three-way bf16 splits of both
+    # operands on the bf16 matrix instructions (csrc/split_bf16.h; error per product below one fp32 rounding)
+    matmul = "f32"
 
     def _hip_s2_ok(self, padded_in):
         w = self.p("conv_a.weight")
@@ -343,6 +351,13 @@ class DownConv(_Weighted):
         if t is None:
             t = self.params[key] = (ops.conv3x3_taps(self.p("conv_aa.weight"), dtype),
                                     ops.conv3x3_taps(self.p("conv_b.weight"), dtype))
+        return t
+
+    def _taps_x3(self):
+        key = self.prefix + "#taps_x3"
+        t = self.params.get(key)
+        if t is None:
+            t = self.params[key] = tuple(ops.split_bf16x3(w) for w in self._taps(torch.float32))
         return t
 
 

@@ -656,6 +656,37 @@ def conv3x3_mish(x_nhwc, taps, bias, pad_h=0, pad_w=0):
     return out
 
 
+def split_bf16x3(t):
+    """fp32 device tensor -> (3, *t.shape) bfloat16: the three-way split of csrc/split_bf16.h (qpwc_split_bf16x3_fwd);
+    out[0] + out[1] + out[2] == t to within 2^-27 |t|.  The weight operands of the *_x3 kernels."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.numel() == 0:
+        raise ValueError("split_bf16x3 takes a non-empty fp32 device tensor")
+    t = t.contiguous()
+    out = torch.empty((3,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+    with torch.cuda.device(t.device):
+        rc = _hip.lib().qpwc_split_bf16x3_fwd(t.data_ptr(), out.data_ptr(), t.numel(), _stream(t))
+    _hip.check(rc)
+    return out
+
+
+def conv3x3_mish_x3(x_nhwc, taps3, bias, pad_h=0, pad_w=0):
+    """conv3x3_mish() for fp32 tensors with the products on the bf16 matrix instructions (bf16x3 split, six partial
+    products, fp32 accumulation: qpwc_conv3x3_mish_x3_fwd).  taps3 = split_bf16x3(conv3x3_taps(weight))."""
+    _check_tensor("x", x_nhwc)
+    if x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous():
+        raise ValueError("conv3x3_mish_x3 needs a dense fp32 channels-last tensor")
+    B, H, W, C = x_nhwc.shape
+    if tuple(taps3.shape) != (3, 9, C, C) or taps3.dtype != torch.bfloat16 or not taps3.is_cuda or \
+            not taps3.is_contiguous() or bias.numel() != C or bias.dtype != torch.float32 or not bias.is_cuda:
+        raise ValueError("taps3 must be a dense (3,9,{0},{0}) bfloat16 device tensor, bias fp32 ({0})".format(C))
+    out = torch.empty((B, H + pad_h, W + pad_w, C), dtype=torch.float32, device=x_nhwc.device)
+    with torch.cuda.device(out.device), _timed("conv3x3_mish_x3", (B, H, W, C)):
+        rc = _hip.lib().qpwc_conv3x3_mish_x3_fwd(x_nhwc.data_ptr(), taps3.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                  B, H, W, C, int(pad_h), int(pad_w), _stream(out))
+    _hip.check(rc)
+    return out
+
+
 def first_conv_taps(weight):
     """torch Conv2d weight (16, 3, 3, 3) of enc.0.conv_a -> (9, 16, 4) fp32 [tap][out][in, slot 3 = 0]."""
     w = weight.float().permute(2, 3, 0, 1).reshape(9, 16, 3)

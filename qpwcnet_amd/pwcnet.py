@@ -118,6 +118,7 @@ class QpwcNet:
         self.dec_chunk_max_pixels = 64 * 256 * 512
         # launch order of flow levels (F) and decoder levels (D) in the two-stream forward, see _forward_two_streams
         self.capture_order = ("F0", "D0", "D1", "D2", "D3", "F1", "F2", "F3", "F4")
+        self._matmul = "f32"
         self.input_shape = tuple(input_shape)
         self.device = torch.device(device)
         self.dtype = dtype
@@ -146,6 +147,22 @@ class QpwcNet:
         if self._df != self.data_format:
             for blk in [self.flow] + self.upflows:
                 blk.flow.out_format = self.data_format   # flow_head writes the (B,2,h,w) output itself
+
+    @property
+    def matmul(self):
+        """Arithmetic of the fp32 matrix products in the convolution kernels: "f32" (fp32 matrix instructions) or
+        "bf16x3" (three-way bf16 splits on the bf16 matrix instructions, csrc/split_bf16.h)."""
+        return self._matmul
+
+    @matmul.setter
+    def matmul(self, v):
+        if v not in ("f32", "bf16x3"):
+            raise ValueError("matmul must be 'f32' or 'bf16x3', got {!r}".format(v))
+        self._matmul = v
+        for layer in self.enc + self.dec:
+            layer.matmul = v
+        for blk in [self.flow] + self.upflows:
+            blk.flow.matmul = v
 
     def _up(self, flo, last=False):
         """Upsample(scale=2.0) between levels (pwcnet.py:55,60).  A channels_first model on the
