@@ -193,6 +193,15 @@ int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
                         const void* dw, const void* pw, const void* bias, void* out,
                         int B, int H, int W, int F, void* stream);
 
+/* qpwc_sepconv3x3_fwd with the pointwise products on the bf16 matrix instructions ("bf16x3", csrc/split_bf16.h: both
+ * operands split into three bf16 values, six partial products, fp32 accumulation; depthwise 3x3 in fp32 as before).
+ * pw3: the (F, Cpad) fp32 matrix of qpwc_sepconv3x3_fwd split by qpwc_split_bf16x3_fwd = (3, F, Cpad) bf16.
+ * Sources: every source but the last a multiple of 4 channels in 16-byte aligned pixels (a last source of fewer than 4
+ * channels is allowed), H*W < 2^24 -- QPWC_E_ALIGN otherwise (use qpwc_sepconv3x3_fwd then). */
+int qpwc_sepconv3x3_x3_fwd(const void* const* src, const int* src_channels, const int64_t* src_pixel_stride,
+                           int n_src, int mish_flags, const void* dw, const void* pw3, const void* bias, void* out,
+                           int B, int H, int W, int F, void* stream);
+
 /* The same SeparableConv2D for fp16 storage (BASELINE configs[4], mixed_float16 in the reference's
  * train.py; non_layers.py:223-231): sources and `out` fp16, dw (C,3,3) and bias (F) fp32, pw (F, Cpad)
  * fp16 with Cpad = ceil(C/32)*32, zero padded.  Depthwise in fp32 on the fp16 input, rounded to fp16

@@ -50,6 +50,9 @@ int cost_volume_to_flow_launch(const void* cvol, float* flow, int B, int H, int 
 int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src, int act,
                           const void* dw, const void* pw, const void* bias, void* out, int B, int H, int W,
                           int F, hipStream_t s);
+int sepconv3x3_x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src, int act,
+                         const void* dw, const void* pw3, const void* bias, void* out, int B, int H, int W, int F,
+                         hipStream_t s);
 int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* strides, int n_src,
                       int act, const void* dw, const void* pw, const void* bias, void* out, int B, int H,
                       int W, int F, hipStream_t s);
@@ -342,6 +345,31 @@ int qpwc_sepconv3x3_fwd(const void* const* src, const int* src_channels,
     if (mish_flags < 0 || mish_flags > 3) return fail(QPWC_E_SHAPE, "mish_flags %d outside [0,3]", mish_flags);
     return sepconv3x3_launch(src, src_channels, src_pixel_stride, n_src, mish_flags, dw, pw, bias, out, B,
                              H, W, F, (hipStream_t)stream);
+}
+
+int qpwc_sepconv3x3_x3_fwd(const void* const* src, const int* src_channels, const int64_t* src_pixel_stride,
+                           int n_src, int mish_flags, const void* dw, const void* pw3, const void* bias, void* out,
+                           int B, int H, int W, int F, void* stream) {
+    if (!src || !src_channels || !src_pixel_stride || !dw || !pw3 || !bias || !out)
+        return fail(QPWC_E_NULL, "null pointer argument");
+    if (n_src < 1 || n_src > 3) return fail(QPWC_E_SHAPE, "n_src %d outside [1,3]", n_src);
+    if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
+    if (F != 16 && F != 32 && F != 64 && F != 128) return fail(QPWC_E_SHAPE, "F=%d not in {16,32,64,128}", F);
+    for (int i = 0; i < n_src; ++i) {
+        if (!src[i]) return fail(QPWC_E_NULL, "null source %d", i);
+        if (src_channels[i] <= 0 || src_pixel_stride[i] < src_channels[i])
+            return fail(QPWC_E_STRIDE, "source %d: %d channels at pixel stride %lld", i, src_channels[i],
+                        (long long)src_pixel_stride[i]);
+        if ((uintptr_t)src[i] % 4) return fail(QPWC_E_ALIGN, "source %d not 4-byte aligned", i);
+        if (overlaps(out, (size_t)B * H * W * F * 4, src[i],
+                     (((size_t)B * H * W - 1) * src_pixel_stride[i] + src_channels[i]) * 4))
+            return fail(QPWC_E_ALIAS, "out overlaps source %d", i);
+    }
+    if ((uintptr_t)out % 16 || (uintptr_t)pw3 % 16 || (uintptr_t)bias % 16 || (uintptr_t)dw % 4)
+        return fail(QPWC_E_ALIGN, "out, pw3, bias must be 16-byte aligned");
+    if (mish_flags < 0 || mish_flags > 3) return fail(QPWC_E_SHAPE, "mish_flags %d outside [0,3]", mish_flags);
+    return sepconv3x3_x3_launch(src, src_channels, src_pixel_stride, n_src, mish_flags, dw, pw3, bias, out, B, H, W, F,
+                                (hipStream_t)stream);
 }
 
 int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels, const int64_t* src_pixel_stride,

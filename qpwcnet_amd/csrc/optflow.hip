@@ -20,6 +20,7 @@
 // 16->2 (no bias) -> * scale   (non_layers.py:238-254, 268-273) in one launch; the
 // normalised 16-channel tile (+1 halo, zero outside the image) lives in LDS.
 #include "common.h"
+#include "split_bf16.h"
 
 namespace qpwc {
 
@@ -1251,6 +1252,8 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
     }
     return check_launch("sepconv3x3_fused_kernel");
 }
+
+#include "sepconv_x3.inc"
 
 // ---------------------------------------------------------------------------
 // flow head.  params (device, fp32): w1[16][16] (out,in) | b1[16] | bn_scale[16] |

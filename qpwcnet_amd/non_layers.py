@@ -367,6 +367,13 @@ class OptFlow(_Weighted):
     times sqrt(h^2 + w^2) of the input's spatial size."""
 
     BN_EPS = 1e-3
+    # fp32 pointwise products: "f32" = fp32 matrix instructions; "bf16x3" = three-way bf16 splits on the bf16 matrix
+    # instructions (qpwc_sepconv3x3_x3_fwd) for the layers where that kernel is the faster one (tools/sepx3bench.py,
+    # B=8: 128 -> 64 at L4 78 -> 66 us, at L3 24.6 -> 21.6; the 128-output first layer 130 -> 139 and the 32- / 16-output
+    # layers +-0 stay on the fp32 instructions: they are bound by staging and the depthwise arithmetic, not the products)
+    matmul = "f32"
+    x3_filters = (64,)
+    x3_min_pixels = 8 * 64 * 128
     # Fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd: depthwise result stays in LDS, pointwise
     # on the fp32 matrix cores) instead of dwconv + library GEMM: False / True = never / always,
     # None = per layer (_fuse_layer).  tools/sepbench.py, B=8 (us, fused vs depthwise kernel + library GEMM):
@@ -380,6 +387,12 @@ class OptFlow(_Weighted):
     # coarse levels the three launches it replaces are bound by their start-up latency, not by their work
     # (8 x 8 tiles with recomputed halos: 2.25 x the matrix work of the 64 -> 32 layer, irrelevant there).
     tail_max_pixels = 16384
+
+    def _pw_x3(self, i):
+        t = self._pw_x3_cache.get(i)
+        if t is None:
+            t = self._pw_x3_cache[i] = ops.split_bf16x3(self._pw_pad[i])
+        return t
 
     @staticmethod
     def _fuse_layer(c_in, n_tiles):
@@ -418,6 +431,7 @@ class OptFlow(_Weighted):
             self._pw_pad84_16 = ops.pad_pointwise(pw84, torch.float16)
             self._dw84 = torch.cat([self._dw[0][:81], self._dw[0].new_zeros((3, 9)), self._dw[0][81:]]).contiguous()
         self._pw_b32 = [b.float().contiguous() for b in self._pw_b]
+        self._pw_x3_cache = {}
         if len(self.filters) == 4:   # dense (F, C) pointwise matrices of the last two layers for qpwc_optflow_tail_fwd
             self._pw3 = self.p("feat.2.pointwise.weight").reshape(self.filters[2], -1).float().contiguous()
             self._pw4 = self.p("feat.3.pointwise.weight").reshape(self.filters[3], -1).float().contiguous()
@@ -488,7 +502,10 @@ class OptFlow(_Weighted):
                 # store Mish(z) when the next consumer is another fused layer (the flow head and the
                 # split depthwise kernel take pre-activation tensors and activate on load)
                 act_out = fuse(i + 1) or (use_tail and i == 1)
-                if fp32:
+                if fp32 and self.matmul == "bf16x3" and not first84 and self._pw_pad[i].shape[0] in self.x3_filters \
+                        and B * H * W >= self.x3_min_pixels and ops.sepconv3x3_x3_applies(src):
+                    pw_i = self._pw_x3(i)
+                elif fp32:
                     pw_i = self._pw_pad84 if first84 else self._pw_pad[i]
                 else:
                     pw_i = self._pw_pad84_16 if first84 else self._pw_pad16[i]

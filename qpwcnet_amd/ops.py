@@ -590,15 +590,17 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False, mish_on_store=F
     -> (B,H,W,F): the pre-activation output, or Mish of it with mish_on_store (the layer's own
     `activation='Mish'` applied once per element; the consumer then loads without Mish)."""
     keep, c_ptrs, c_ch, c_st, B, H, W, C = _dw_sources(sources)
-    F_ = pw_padded.shape[0]
+    F_ = pw_padded.shape[-2]
     w = dw.reshape(-1, 9)
-    if w.shape[0] != C or pw_padded.shape[1] != (C + 31) // 32 * 32 or bias.numel() != F_:
+    if w.shape[0] != C or pw_padded.shape[-1] != (C + 31) // 32 * 32 or bias.numel() != F_:
         raise ValueError("weight shapes do not match C = {}".format(C))
     flags = int(bool(mish_on_load)) | (2 if mish_on_store else 0)
     if keep[0].dtype == torch.float16:
         return _sepconv3x3_f16(keep, c_ptrs, c_ch, c_st, w, pw_padded, bias, flags, B, H, W, C, F_)
     if keep[0].dtype != torch.float32:
         raise ValueError("sepconv3x3 takes fp32 or fp16 sources")
+    if pw_padded.dtype == torch.bfloat16:
+        return _sepconv3x3_x3(keep, c_ptrs, c_ch, c_st, w, pw_padded, bias, flags, B, H, W, C)
     for t in (w, pw_padded, bias):
         if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
             raise ValueError("weights must be dense fp32 device tensors")
@@ -607,6 +609,36 @@ def sepconv3x3(sources, dw, pw_padded, bias, mish_on_load=False, mish_on_store=F
         rc = _hip.lib().qpwc_sepconv3x3_fwd(c_ptrs, c_ch, c_st, len(keep), flags,
                                              w.data_ptr(), pw_padded.data_ptr(), bias.data_ptr(),
                                              out.data_ptr(), B, H, W, F_, _stream(out))
+    _hip.check(rc)
+    return out
+
+
+def sepconv3x3_x3_applies(sources):
+    """True when qpwc_sepconv3x3_x3_fwd takes these fp32 sources: every source but the last a multiple of 4 channels
+    in 16-byte aligned pixels (a last source of fewer than 4 channels is allowed), H * W < 2^24."""
+    n = len(sources)
+    for i, t in enumerate(sources):
+        aligned = t.shape[3] % 4 == 0 and t.stride(2) % 4 == 0 and t.data_ptr() % 16 == 0
+        if not aligned and (i + 1 < n or t.shape[3] >= 4 or t.shape[0] * t.shape[1] * t.shape[2] * t.stride(2) < 8):
+            return False
+        if t.shape[1] * t.shape[2] >= 1 << 24 or t.stride(2) >= 1 << 24 or t.shape[1] * t.shape[2] * t.stride(2) >= 1 << 31:
+            return False
+    return all(t.dtype == torch.float32 for t in sources)
+
+
+def _sepconv3x3_x3(keep, c_ptrs, c_ch, c_st, w, pw3, bias, flags, B, H, W, C):
+    """fp32 with the pointwise products as bf16x3 splits (qpwc_sepconv3x3_x3_fwd): pw3 = split_bf16x3(pad_pointwise(..))
+    = (3, F, Cpad) bfloat16, dw / bias fp32."""
+    F_ = pw3.shape[1]
+    if pw3.dim() != 3 or pw3.shape[0] != 3 or not pw3.is_cuda or not pw3.is_contiguous():
+        raise ValueError("pw3 must be a dense (3, F, Cpad) bfloat16 device tensor")
+    for t in (w, bias):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("dw / bias must be dense fp32 device tensors")
+    out = torch.empty((B, H, W, F_), dtype=torch.float32, device=keep[0].device)
+    with torch.cuda.device(out.device), _timed("sepconv3x3_x3", (B, H, W, C, F_)):
+        rc = _hip.lib().qpwc_sepconv3x3_x3_fwd(c_ptrs, c_ch, c_st, len(keep), flags, w.data_ptr(), pw3.data_ptr(),
+                                                bias.data_ptr(), out.data_ptr(), B, H, W, F_, _stream(out))
     _hip.check(rc)
     return out
 
