@@ -69,6 +69,25 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 #ifndef QPWC_ENC_NT
 #define QPWC_ENC_NT 1
 #endif
+// Explicit operand prefetch in the wide fp32 kernels (round 3): a kernel's (tap, 16-channel chunk) steps as one flat
+// unrolled loop, the TH ds_read_b128 of step i + 1 issued before the 4 TH matrix instructions of step i, a
+// sched_barrier per step.  As the compiler places them the reads go out 1-4 matrix instructions (32-128 cycles) before
+// their first use and every step ends in an `s_waitcnt lgkmcnt(0)` that one wave per SIMD (the 128- and 256-channel
+// levels) has nothing to hide behind.  Measured in one call (tools/encbench.py, tools/step_time.py, three interleaved
+// runs): stride-1 layers C = 64 / 128 / 256: 33.3 / 30.4 / 33.2 -> 29.7 / 29.7 / 30.1 us (two steps ahead: 32.0 / 29.4 /
+// 30.2), step 1.2006 -> 1.1826 ms -- kept (QPWC_ENC_PIPE = 1).  The stride-2 layers do not move (17.4-20.6 us either
+// way, step 1.1816 vs 1.1809) and the decoder's transposed convolution gets 7 us SLOWER per step with it (1.1886 vs
+// 1.1816: on the second queue, beside the coarse flow levels, see QpwcNet.dec_chunks) -- both stay as the compiler
+// schedules them.
+#ifndef QPWC_S2_PIPE
+#define QPWC_S2_PIPE 0
+#endif
+#ifndef QPWC_UPCONV_PIPE
+#define QPWC_UPCONV_PIPE 0
+#endif
+#ifndef QPWC_ENC_PIPE
+#define QPWC_ENC_PIPE 1   // operand reads of the wide fp32 kernels issued this many steps ahead (0 = as the compiler places them)
+#endif
 #ifdef QPWC_ENC_STAMP
 // diagnostic build only (make ab ABSRC=encoder ABFLAGS=-DQPWC_ENC_STAMP; tools/enc_census.py): per workgroup of
 // the narrow kernel: start, inputs landed, staged (after the barrier), matrix work done, end, HW_ID | XCC_ID << 32
@@ -297,6 +316,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
 #pragma unroll 1
     for (int kb = 0; kb < NKB; ++kb) {
         if (kb + 1 < NKB) load_w(wn, kb + 1);
+#if QPWC_ENC_PIPE
+        // one step = (tap, 16-channel chunk): TH ds_read_b128 feed 4 TH matrix instructions; the reads of step i + 1
+        // are issued before the matrix instructions of step i (the wide levels run one wave per SIMD: nothing else
+        // covers the LDS latency)
+        constexpr int RD = QPWC_ENC_PIPE;       // steps ahead
+        f32x4e bb[RD + 1][TH];
+        auto read_b = [&](f32x4e (&bv)[TH], int i) __attribute__((always_inline)) {
+            const int tap = i >> 1, kc = i & 1, ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int m = 0; m < TH; ++m) {
+                const int hp = (m + ky) * kEcHW + n + kx;
+                const int q = 8 * kb + 4 * kc + g;
+                bv[m] = *reinterpret_cast<const f32x4e*>(in_s + hp * C + 4 * (q ^ (hp & 15)));
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < RD; ++i) read_b(bb[i], i);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            if (i + RD < 18) read_b(bb[(i + RD) % (RD + 1)], i + RD);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < TH; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i >> 1][i & 1][t], bb[i % (RD + 1)][m][t], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -316,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
                         for (int m = 0; m < TH; ++m)
                             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[m][t], acc[m], 0, 0, 0);
                 }
+#endif
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -646,6 +694,30 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
 #pragma unroll 1
     for (int kb = 0; kb < NKB; ++kb) {
         if (kb + 1 < NKB) load_w(wn, kb + 1);
+#if QPWC_UPCONV_PIPE
+        // one step = (tap, 16-channel chunk); the operand reads of step i + 1 go out before the matrix instructions of
+        // step i (as in conv3x3_mish_wide_kernel)
+        f32x4e bb[2][TH];
+        auto read_b = [&](f32x4e (&bv)[TH], int i) __attribute__((always_inline)) {
+            const int t = i >> 1, kc = i & 1;
+#pragma unroll
+            for (int m = 0; m < TH; ++m) {
+                const int hp = (m + 1 + offy[t]) * kEcHW + n + 1 + offx[t];
+                bv[m] = *reinterpret_cast<const f32x4e*>(in_s + hp * C + 4 * ((8 * kb + 4 * kc + g) ^ (hp & 15)));
+            }
+        };
+        read_b(bb[0], 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i + 1 < 8) read_b(bb[(i + 1) & 1], i + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < TH; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i >> 1][i & 1][j], bb[i & 1][m][j], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -662,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
                     for (int m = 0; m < TH; ++m)
                         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][kc][j], bv[m][j], acc[m], 0, 0, 0);
             }
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1068,6 +1141,30 @@ __global__ __launch_bounds__(256, (2 * (2 * TH + 1) * (kEcTW + 1) * CI * 4 > 80 
 #pragma unroll 1
     for (int kb = 0; kb < NKB; ++kb) {
         if (kb + 1 < NKB) load_w(wn, kb + 1);
+#if QPWC_S2_PIPE
+        // one step = (tap, 16-channel chunk); the operand reads of step i + 1 go out before the matrix instructions of
+        // step i (as in conv3x3_mish_wide_kernel)
+        f32x4e bb[2][TH];
+        auto read_b = [&](f32x4e (&bv)[TH], int i) __attribute__((always_inline)) {
+            const int tap = i >> 1, kc = i & 1, ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int m = 0; m < TH; ++m) {
+                const int pix = ((kx & 1) * IH + 2 * m + ky) * PW + n + (kx >> 1);
+                bv[m] = *reinterpret_cast<const f32x4e*>(in_s + pix * CI + 4 * slot(8 * kb + 4 * kc + g, pix));
+            }
+        };
+        read_b(bb[0], 0);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            if (i + 1 < 18) read_b(bb[(i + 1) & 1], i + 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < TH; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i >> 1][i & 1][t], bb[i & 1][m][t], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1086,6 +1183,7 @@ __global__ __launch_bounds__(256, (2 * (2 * TH + 1) * (kEcTW + 1) * CI * 4 > 80 
                         for (int m = 0; m < TH; ++m)
                             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[m][t], acc[m], 0, 0, 0);
                 }
+#endif
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
