@@ -1344,7 +1344,8 @@ static constexpr int lds_mode() { return 1; }
 // Region size policy of the workgroup-shared fp32 kernels (measured, tools/kbench.py --regions):
 // 16 x 16 regions need one workgroup of 16 waves per CU to be worth it.
 #ifndef QPWC_R16_MIN_WARP
-#define QPWC_R16_MIN_WARP 256    // 16 x 16 regions per launch from which the fused front end takes them
+#define QPWC_R16_MIN_WARP 512    // 16 x 16 regions per launch from which the fused front end takes them (two rounds of
+                                 // one-per-CU workgroups; see use_regions16)
 #endif
 #ifndef QPWC_R16_MIN_PLAIN
 #define QPWC_R16_MIN_PLAIN (1 << 30)   // the plain cost volume: never (B=8 L3 19.4 vs 17.6 us, config 4 L1-L3 +5 ... +14 %:
@@ -1361,6 +1362,10 @@ static bool use_regions16(int B, int H, int W, int C, bool warp) {
     // 32-channel step (C = 32, the finest level) the three phases are of comparable length and the 8 x 8 kernel's
     // three workgroups per CU win (B=8 L4: 48.7 vs 52.7 us); from two steps on the staging share grows and the
     // 16 x 16 regions do (L3, C = 64: 22.3 vs 26.3-27.5 us; config 4's L1-L3: -8 ... -10 %).
+    // A launch of ONE round (256 regions: config 2's L3) is left to the 8 x 16 regions since round 3: alone it is 1 us
+    // slower there (23.5 vs 22.4 us), but inside the two-queue forward the finest decoder level runs beside this launch
+    // (QpwcNet.dec_chunks) and a 148 KB workgroup cannot share a CU with that kernel's 46 KB ones, a 75 KB one can:
+    // 50.7 -> ~45 us in the step's kernel trace, step 1.2027 -> 1.1988 ms (three interleaved pairs of one call).
     return C >= 64 && regs16 >= (warp ? QPWC_R16_MIN_WARP : QPWC_R16_MIN_PLAIN);
 }
 
@@ -1389,7 +1394,7 @@ static int launch_lds16(const float* prv, const float* nxt, const float* flo, fl
 }
 
 #ifndef QPWC_R8X16_ANYC
-#define QPWC_R8X16_ANYC 0     // A/B builds: 8 x 16 regions for every channel count the 16 x 16 form does not take
+#define QPWC_R8X16_ANYC 1     // 8 x 16 regions for every channel count the 16 x 16 form does not take (0: C = 32 only)
 #endif
 #ifndef QPWC_R8X16_MIN
 #define QPWC_R8X16_MIN 512    // 8 x 16 regions per launch from which the single-step fused front end takes them (2 per CU)

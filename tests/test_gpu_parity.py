@@ -351,7 +351,8 @@ def test_matrix_core_kernels_ragged_edges(shape):
 
 
 @pytest.mark.parametrize("shape", [(32, 36, 52, 32), (40, 30, 44, 64), (20, 33, 47, 128), (8, 128, 256, 32),
-                                   (32, 36, 52, 64), (30, 33, 47, 128), (2, 150, 290, 32), (8, 40, 290, 64)])
+                                   (32, 36, 52, 64), (30, 33, 47, 128), (2, 150, 290, 32), (8, 40, 290, 64),
+                                   (32, 50, 70, 64), (44, 33, 60, 128), (48, 33, 47, 96)])   # >= 512 16 x 16 regions; 8 x 16 at C = 96
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
 def test_fused_front_end_on_the_matrix_cores_ragged_edges_and_far_flows(shape, dtype):
     """qpwc_warp_cost_volume_fwd where the workgroup-shared matrix-core kernel takes it (>= 256 regions, C % 32 == 0):
