@@ -553,6 +553,34 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
             "note": "{} hipGraph replays (batch {} each) on as many streams; not the headline value".format(n_fly, B)}
         del lanes[1:]
 
+    # ---- the same step with the fp32 matrix products as three-way bf16 splits on the bf16 matrix instructions
+    # (QpwcNet.matmul = "bf16x3", csrc/split_bf16.h): reported BESIDE the headline, which stays on the fp32 matrix
+    # instructions; same inputs, same K steps, flows compared with the headline's
+    if headline and graphs is not None and world == 1 and dtype == "f32" and not args.no_inflight:
+        ref_flows = [f.clone() for f in graphs[0].outputs]
+        model.matmul = "bf16x3"
+        try:
+            with torch.no_grad():
+                model(pairs)
+            gx = GraphedForward(model, pairs, epilogue=epe_of, warmup=0)
+            for _ in range(max(2, warmup)):
+                gx.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                gx.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            res["matmul_bf16x3"] = {
+                "value": B * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3,
+                "max_abs_flow_diff_vs_headline_px": max(float((a - b).abs().max()) for a, b in zip(gx.outputs, ref_flows)),
+                "note": "opt-in arithmetic (encoder 3x3 convolutions and the 64-output SeparableConv2D layers): six bf16 "
+                        "partial products per fp32 product, fp32 accumulate; not the headline value"}
+            del gx
+        finally:
+            model.matmul = "f32"
+        del ref_flows
+
     # ---- live rooflines (single stream, HIP events)
     blocks, hot = rooflines(model, pairs, B, hw, dtype, tdtype, dev, args, copy_gbs)
     # the dominant hot-path launch of THIS step: the fused WarpV2 + cost volume where UpFlow uses it at L4, the
@@ -617,6 +645,10 @@ def compact_line(full):
     if "serving_throughput" in full:
         st = full["serving_throughput"]
         line["serving_throughput"] = {"value": _r(st["value"]), "batches_in_flight": st["batches_in_flight"]}
+    if "matmul_bf16x3" in full:
+        mx = full["matmul_bf16x3"]
+        line["matmul_bf16x3"] = {"value": _r(mx["value"]), "ms_per_step": _r(mx["ms_per_step"]),
+                                 "max_abs_flow_diff_vs_headline_px": _r(mx["max_abs_flow_diff_vs_headline_px"], 3)}
     lib = full.get("library") or {}
     line["library"] = "{} v{}{}".format(lib.get("build"), lib.get("version"), "" if lib.get("product") else " NOT-PRODUCT")
     line["detail"] = full.get("detail_file")

@@ -79,6 +79,9 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 // way, step 1.1816 vs 1.1809) and the decoder's transposed convolution gets 7 us SLOWER per step with it (1.1886 vs
 // 1.1816: on the second queue, beside the coarse flow levels, see QpwcNet.dec_chunks) -- both stay as the compiler
 // schedules them.
+#ifndef QPWC_ENC16_PIPE
+#define QPWC_ENC16_PIPE 1   // the fp16 wide kernel: a tap's operand reads one tap ahead (0 = as the compiler places them)
+#endif
 #ifndef QPWC_S2_PIPE
 #define QPWC_S2_PIPE 0
 #endif
@@ -496,6 +499,29 @@ __global__ __launch_bounds__(256) void conv3x3_mish_f16_kernel(const __half* __r
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
             if (kb + 1 < NKB) load_w(wn, kb + 1);
+#if QPWC_ENC16_PIPE
+            // one step = one tap: TH ds_read_b128 feed TH matrix instructions of 16 cycles each; the reads of tap
+            // t + 1 go out before the matrix instructions of tap t (round 3: as the compiler placed them every matrix
+            // instruction waited for its own read -- 33 us for a layer whose bytes and products are 4 us each)
+            f16x8e bb[2][TH];
+            auto read_b = [&](f16x8e (&bv)[TH], int tap) __attribute__((always_inline)) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+                for (int r = 0; r < TH; ++r) {
+                    const int hp = (r + ky) * kEcHW + n + kx;
+                    bv[r] = *reinterpret_cast<const f16x8e*>(in_s + hp * CP + 8 * f16_slot<CP>(4 * kb + g, hp));
+                }
+            };
+            read_b(bb[0], 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) read_b(bb[(tap + 1) & 1], tap + 1);
+#pragma unroll
+                for (int r = 0; r < TH; ++r)
+                    acw[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[tap], bb[tap & 1][r], acw[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - 3 * ky;
@@ -506,6 +532,7 @@ __global__ __launch_bounds__(256) void conv3x3_mish_f16_kernel(const __half* __r
                     acw[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[tap], bv, acw[r], 0, 0, 0);
                 }
             }
+#endif
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) wv[tap] = wn[tap];
         }
