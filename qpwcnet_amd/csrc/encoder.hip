@@ -82,6 +82,13 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 #ifndef QPWC_ENC16_PIPE
 #define QPWC_ENC16_PIPE 1   // the fp16 wide kernel: a tap's operand reads one tap ahead (0 = as the compiler places them)
 #endif
+// (the same one / two taps ahead in the fp16 transposed and stride-2 kernels: config 5's step 1.709 vs 1.706 ms -- off)
+#ifndef QPWC_UPCONV16_PIPE
+#define QPWC_UPCONV16_PIPE 0
+#endif
+#ifndef QPWC_S2_16_PIPE
+#define QPWC_S2_16_PIPE 0
+#endif
 #ifndef QPWC_S2_PIPE
 #define QPWC_S2_PIPE 0
 #endif
@@ -619,6 +626,149 @@ __global__ __launch_bounds__(256) void conv3x3_mish_f16_kernel(const __half* __r
     (void)NSL;
 }
 
+// ---------------------------------------------------------------------------
+// The narrow levels of the fp16 layer (C = 16 / 32), round 3.  The kernel above runs them at 60 / 34 us for 64 frames
+// (config 5) where their bytes allow 17 / 8: half of every C = 16 matrix instruction multiplies zeros, the weights are
+// fetched again for every tap and every matrix instruction waits for its own operand read.  Here (the structure of
+// conv3x3_mish_x3_narrow_kernel): 16 x 16 pixel tile, a wave owns four tile rows and ALL outputs, the weights of the
+// whole layer sit in registers (C = 32: 9 taps x 2 output blocks; C = 16: 5 tap PAIRS -- k-slots g = 0, 1 carry tap 2j,
+// g = 2, 3 tap 2j + 1, so no lane multiplies padding except in the tenth half), and a tap's four operand reads go out
+// one tap ahead of its matrix instructions.
+template <int C>
+__device__ __forceinline__ int f16n_slot(int q, int hp) {
+    return C == 16 ? (q ^ ((hp >> 3) & 1)) : (q ^ ((0 - (hp >> 2)) & 3));
+}
+
+template <int C>
+__global__ __launch_bounds__(256, C == 16 ? 4 : 3) void conv3x3_mish_f16_narrow_kernel(
+    const __half* __restrict__ x, const __half* __restrict__ weight, const float* __restrict__ bias,
+    __half* __restrict__ out, int H, int W, int pad_h, int pad_w, int tiles_x, int tiles_y) {
+    constexpr int TH = 16, RW = 4, HWD = kEcTW + 2;
+    constexpr int NQ = C / 8, NH = (TH + 2) * HWD;
+    constexpr int NST = (NH * NQ + 255) / 256;
+    constexpr int NFT = C / 16;
+    __shared__ __attribute__((aligned(16))) __half in_s[NH * C];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kEcTW, Y0 = ty * TH;
+    const __half* xb = x + (int64_t)b * H * W * C;
+    const int Ho = H + pad_h, Wo = W + pad_w;
+    __half* ob = out + (int64_t)b * Ho * Wo * C;
+    {
+        uint4 st[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
+            st[it] = (idx < NH * NQ && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                         ? *reinterpret_cast<const uint4*>(xb + ((int64_t)gy * W + gx) * C + 8 * q)
+                         : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int hp = idx / NQ, q = idx - hp * NQ;
+            if (idx < NH * NQ) *reinterpret_cast<uint4*>(in_s + hp * C + 8 * f16n_slot<C>(q, hp)) = st[it];
+        }
+    }
+    // steps: C = 32: the 9 taps (lane's k-slot = channels 8g .. 8g+7); C = 16: 5 tap pairs (tap 2j + (g >> 1), channels
+    // 8 (g & 1) .. + 7; the tenth half has zero weights and reads a valid pixel)
+    constexpr int NS = C == 16 ? 5 : 9;
+    const int gh = C == 16 ? (g >> 1) : 0, gq = C == 16 ? (g & 1) : g;
+    f16x8e wv[NS][NFT];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int tap = C == 16 ? 2 * j + gh : j;
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            wv[j][ft] = f16x8e{0, 0, 0, 0, 0, 0, 0, 0};
+            if (tap < 9) wv[j][ft] = *reinterpret_cast<const f16x8e*>(weight + ((int64_t)tap * C + 16 * ft + n) * C + 8 * gq);
+        }
+    }
+    f32x4e acc[RW][NFT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) acc[r][ft] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    f16x8e bb[2][RW];
+    auto read_b = [&](f16x8e (&bv)[RW], int j) __attribute__((always_inline)) {
+        const int t0 = C == 16 ? 2 * j + gh : j;
+        const int tap = t0 < 9 ? t0 : 8;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int hp = (RW * wave + r + ky) * HWD + n + kx;
+            bv[r] = *reinterpret_cast<const f16x8e*>(in_s + hp * C + 8 * f16n_slot<C>(gq, hp));
+        }
+    };
+    read_b(bb[0], 0);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        if (j + 1 < NS) read_b(bb[(j + 1) & 1], j + 1);
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                acc[r][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[j][ft], bb[j & 1][r], acc[r][ft], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- bias + Mish, one rounding to fp16: lane = pixel n of tile row RW wave + r, outputs 16 ft + 4g .. + 3 ----
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int gy = Y0 + RW * wave + r, gx = X0 + n;
+            if (gy < H && gx < W) {
+                f16x4e o;
+                o[0] = (_Float16)enc_mishf(acc[r][ft][0] + bq.x);
+                o[1] = (_Float16)enc_mishf(acc[r][ft][1] + bq.y);
+                o[2] = (_Float16)enc_mishf(acc[r][ft][2] + bq.z);
+                o[3] = (_Float16)enc_mishf(acc[r][ft][3] + bq.w);
+                *reinterpret_cast<f16x4e*>(ob + ((int64_t)gy * Wo + gx) * C + 16 * ft + 4 * g) = o;
+            }
+        }
+    }
+    // ---- zero border of the padded output (C / 8 sixteen-byte chunks per pixel) ----
+    if (pad_w > 0 && X0 + kEcTW >= W) {
+        for (int i = tid; i < TH * pad_w * NQ; i += 256) {
+            const int q = i % NQ, r = i / NQ, col = r % pad_w, row = r / pad_w;
+            const int gy = Y0 + row;
+            if (gy < H) *reinterpret_cast<uint4*>(ob + ((int64_t)gy * Wo + W + col) * C + 8 * q) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    if (pad_h > 0 && Y0 + TH >= H) {
+        const int x_end = (X0 + kEcTW >= W) ? Wo : X0 + kEcTW;   // the corner belongs to the last tile
+        for (int i = tid; i < pad_h * (x_end - X0) * NQ; i += 256) {
+            const int q = i % NQ, r = i / NQ, col = r % (x_end - X0), row = r / (x_end - X0);
+            *reinterpret_cast<uint4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + 8 * q) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
+#ifndef QPWC_ENC16_NARROW
+#define QPWC_ENC16_NARROW 1   // 0: the narrow levels on conv3x3_mish_f16_kernel (A/B)
+#endif
+template <int C>
+static int conv3x3_mish_f16_narrow_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H,
+                                          int W, int pad_h, int pad_w, hipStream_t s) {
+    const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + 15) / 16;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles > INT32_MAX) {
+        set_error("conv3x3_mish_f16: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((conv3x3_mish_f16_narrow_kernel<C>), dim3((unsigned)n_tiles), dim3(256), 0, s, (const __half*)x,
+                       (const __half*)weight, (const float*)bias, (__half*)out, H, W, pad_h, pad_w, tiles_x, tiles_y);
+    return check_launch("conv3x3_mish_f16_narrow_kernel");
+}
+
 template <int C, int TH>
 static int conv3x3_mish_f16_launch_t(const void* x, const void* weight, const void* bias, void* out, int B, int H,
                                      int W, int pad_h, int pad_w, hipStream_t s) {
@@ -638,8 +788,10 @@ static int conv3x3_mish_f16_launch_t(const void* x, const void* weight, const vo
 int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                             int C, int pad_h, int pad_w, hipStream_t s) {
     switch (C) {
-        case 16: return conv3x3_mish_f16_launch_t<16, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
-        case 32: return conv3x3_mish_f16_launch_t<32, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+        case 16: return QPWC_ENC16_NARROW ? conv3x3_mish_f16_narrow_launch<16>(x, weight, bias, out, B, H, W, pad_h, pad_w, s)
+                                          : conv3x3_mish_f16_launch_t<16, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
+        case 32: return QPWC_ENC16_NARROW ? conv3x3_mish_f16_narrow_launch<32>(x, weight, bias, out, B, H, W, pad_h, pad_w, s)
+                                          : conv3x3_mish_f16_launch_t<32, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
         case 64: return conv3x3_mish_f16_launch_t<64, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
         case 128: return conv3x3_mish_f16_launch_t<128, 8>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
         case 256: return conv3x3_mish_f16_launch_t<256, 4>(x, weight, bias, out, B, H, W, pad_h, pad_w, s);
@@ -867,6 +1019,25 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
 #pragma unroll 1
     for (int kb = 0; kb < NKB; ++kb) {
         if (kb + 1 < NKB) load_w(wn, kb + 1);
+#if QPWC_UPCONV16_PIPE
+        // a tap's TH operand reads go out one tap ahead of its matrix instructions (as in conv3x3_mish_f16_kernel)
+        f16x8e bb[2][TH];
+        auto read_b = [&](f16x8e (&bv)[TH], int t) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < TH; ++m) {
+                const int hp = (m + 1 + offy[t]) * kEcHW + n + 1 + offx[t];
+                bv[m] = *reinterpret_cast<const f16x8e*>(in_s + hp * C + 8 * f16_slot<C>(4 * kb + g, hp));
+            }
+        };
+        read_b(bb[0], 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t + 1 < 4) read_b(bb[(t + 1) & 1], t + 1);
+#pragma unroll
+            for (int m = 0; m < TH; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[t], bb[t & 1][m], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -875,6 +1046,7 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
                 const f16x8e bv = *reinterpret_cast<const f16x8e*>(in_s + hp * C + 8 * f16_slot<C>(4 * kb + g, hp));
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[t], bv, acc[m], 0, 0, 0);
             }
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) wv[t] = wn[t];
     }
@@ -1344,6 +1516,28 @@ __global__ __launch_bounds__(256) void conv3x3s2_mish_f16_kernel(const __half* _
 #pragma unroll 1
     for (int kb = 0; kb < NKB; ++kb) {
         if (kb + 1 < NKB) load_w(wn, kb + 1);
+#if QPWC_S2_16_PIPE
+        // operand reads two taps ahead of their matrix instructions (RW of 16 cycles per tap: one tap would not cover
+        // the LDS latency)
+        f16x8e bb[3][RW];
+        auto read_b = [&](f16x8e (&bv)[RW], int tap) __attribute__((always_inline)) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int hp = ((kx & 1) * IH + 2 * (r0 + r) + ky) * PW + n + (kx >> 1);
+                bv[r] = *reinterpret_cast<const f16x8e*>(in_s + hp * CP + 8 * f16_slot<CP>(4 * kb + g, hp));
+            }
+        };
+        read_b(bb[0], 0);
+        read_b(bb[1], 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 2 < 9) read_b(bb[(tap + 2) % 3], tap + 2);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[tap], bb[tap % 3][r], acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
@@ -1354,6 +1548,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_mish_f16_kernel(const __half* _
                 acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[tap], bv, acc[r], 0, 0, 0);
             }
         }
+#endif
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) wv[tap] = wn[tap];
     }

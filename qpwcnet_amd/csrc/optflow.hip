@@ -1063,6 +1063,13 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_f16_kernel(
                                  // 21.6, 10.5 vs 11.0 -- but F=64 170.8 vs 155.2 (172 registers: 2 instead of 3 waves per SIMD)
                                  // and F=128 266.8 vs 247.8: the narrow layers only, as in fp32
 #endif
+#ifndef QPWC_SC16_DIRECT
+#define QPWC_SC16_DIRECT 0   // lab note (experimental/sepconv_f16_direct.inc): parity-green, slower -- never in the product build
+#endif
+#if QPWC_SC16_DIRECT
+#include "experimental/sepconv_f16_direct.inc"
+#endif
+
 template <int F>
 static void sepconv_f16_dispatch(const DwSrc& d, bool wide, int act, const float* dw, const __half* pw,
                                  const float* bias, __half* out, int H, int W, int C, int cpad, int tiles_x,
@@ -1128,6 +1135,18 @@ int sepconv3x3_f16_launch(const void* const* srcs, const int* chans, const int64
             default: set_error("sepconv3x3_f16: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
         }
         return check_launch("sepconv3x3_f16_stream_kernel");
+    }
+#endif
+#if QPWC_SC16_DIRECT
+    if (F >= QPWC_SC16_DIRECT_MINF) {
+        switch (F) {
+            case 128: sepconv_f16_direct_dispatch<128>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+            case 64: sepconv_f16_direct_dispatch<64>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+            case 32: sepconv_f16_direct_dispatch<32>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+            case 16: sepconv_f16_direct_dispatch<16>(d, wide, act, fdw, hp, fb, (__half*)out, H, W, C, cpad, tiles_x, tiles_y, grid, s); break;
+            default: set_error("sepconv3x3_f16: unsupported filter count %d (16/32/64/128)", F); return QPWC_E_SHAPE;
+        }
+        return check_launch("sepconv3x3_f16_direct_kernel");
     }
 #endif
     switch (F) {
