@@ -334,6 +334,8 @@ def test_bench_line_fits_the_drivers_window():
                               "sample": "s" * 300, "sample_short": "2 pairs, full net, median of 3 passes"},
                 per_level_epe_vs_oracle=[2.69e-07] * 6, per_level_epe_vs_ground_truth=[1.0] * 6,
                 serving_throughput={"value": 7232.9, "batches_in_flight": 2, "note": "n" * 100},
+                matmul_bf16x3={"value": 6967.123456, "unit": "pairs/s", "ms_per_step": 1.14823456,
+                               "max_abs_flow_diff_vs_headline_px": 1.3113e-06, "note": "n" * 200},
                 library={"path": "/p", "version": 200, "build": "libqpwc_hip gfx950 product (no environment switches)",
                          "product": True},
                 detail_file="bench_detail.json",
@@ -350,6 +352,8 @@ def test_bench_line_fits_the_drivers_window():
     for v in ("533.5524", "18117.76", '"extra_configs"', '"whole_step"'):
         assert v in tail
     assert tail.count('"ms_per_step"') >= 2 and tail.count('"roofline"') >= 2
+    # the opt-in arithmetic's leg travels beside the headline, never as `value`
+    assert d["matmul_bf16x3"]["value"] == 6967.1 and d["value"] == 6624.861 and "note" not in d["matmul_bf16x3"]
 
 
 def test_decoder_side_stream_mapping_must_not_return_to_an_earlier_stream():
@@ -368,3 +372,38 @@ def test_decoder_side_stream_mapping_must_not_return_to_an_earlier_stream():
     with mock.patch("torch.cuda.current_stream", return_value=None):
         with pytest.raises(ValueError, match="non-decreasing"):
             m._forward_two_streams([Enc()], 8)
+
+
+def test_matmul_switch_reaches_every_convolution_block_and_rejects_unknown_modes():
+    """Round 3: QpwcNet.matmul = "bf16x3" (csrc/split_bf16.h) is a property that sets the mode on the encoder, decoder
+    and OptFlow blocks; the default is the fp32 matrix instructions and nothing else is accepted."""
+    from qpwcnet_amd.pwcnet import QpwcNet
+
+    class Blk:
+        matmul = "f32"
+
+    class Up:
+        def __init__(self):
+            self.flow = Blk()
+    m = QpwcNet.__new__(QpwcNet)
+    m._matmul, m.enc, m.dec, m.flow, m.upflows = "f32", [Blk(), Blk()], [Blk()], Up(), [Up(), Up()]
+    assert m.matmul == "f32" and non_layers.DownConv.matmul == "f32" and non_layers.OptFlow.matmul == "f32"
+    m.matmul = "bf16x3"
+    assert all(b.matmul == "bf16x3" for b in m.enc + m.dec) and all(u.flow.matmul == "bf16x3" for u in m.upflows + [m.flow])
+    with pytest.raises(ValueError, match="matmul"):
+        m.matmul = "bf16"
+    assert m.matmul == "bf16x3"
+
+
+def test_sepconv_x3_source_rule_mirrors_the_c_side():
+    """qpwc_sepconv3x3_x3_fwd takes the 16-byte staging path only: every source but the last a multiple of 4 channels in
+    16-byte aligned pixels, a last source of fewer than 4 channels allowed (sepconv_x3_sources_ok in csrc/sepconv_x3.inc)."""
+    z = lambda c: torch.zeros(2, 8, 16, c)
+    assert ops.sepconv3x3_x3_applies([z(84), z(32), z(2)])
+    assert ops.sepconv3x3_x3_applies([z(128)])
+    assert not ops.sepconv3x3_x3_applies([z(7), z(8)])          # an odd source in front
+    assert not ops.sepconv3x3_x3_applies([z(8), z(6)])          # a last source of >= 4 channels must be aligned too
+    assert not ops.sepconv3x3_x3_applies([z(8).half()])         # fp16 storage has its own kernel
+    wide = torch.zeros(2, 8, 16, 40)
+    assert ops.sepconv3x3_x3_applies([wide[..., 8:24]])         # a 16-byte aligned channel slice of a wider buffer
+    assert not ops.sepconv3x3_x3_applies([wide[..., 2:18]])
