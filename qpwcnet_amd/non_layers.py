@@ -369,10 +369,11 @@ class OptFlow(_Weighted):
     BN_EPS = 1e-3
     # fp32 pointwise products: "f32" = fp32 matrix instructions; "bf16x3" = three-way bf16 splits on the bf16 matrix
     # instructions (qpwc_sepconv3x3_x3_fwd) for the layers where that kernel is the faster one (tools/sepx3bench.py,
-    # B=8: 128 -> 64 at L4 78 -> 66 us, at L3 24.6 -> 21.6; the 128-output first layer 130 -> 139 and the 32- / 16-output
-    # layers +-0 stay on the fp32 instructions: they are bound by staging and the depthwise arithmetic, not the products)
+    # B=8, us: 118 -> 128 at L4 134 -> 106, at L3 45.5 -> 36.2; 128 -> 64 at L4 78 -> 66, at L3 24.6 -> 21.6; the 32- /
+    # 16-output layers +-0 stay on the fp32 instructions: they are bound by staging and the depthwise stage, not by
+    # their products)
     matmul = "f32"
-    x3_filters = (64,)
+    x3_filters = (128, 64)
     x3_min_pixels = 8 * 64 * 128
     # Fused depthwise+pointwise kernel (qpwc_sepconv3x3_fwd: depthwise result stays in LDS, pointwise
     # on the fp32 matrix cores) instead of dwconv + library GEMM: False / True = never / always,
@@ -388,10 +389,11 @@ class OptFlow(_Weighted):
     # (8 x 8 tiles with recomputed halos: 2.25 x the matrix work of the 64 -> 32 layer, irrelevant there).
     tail_max_pixels = 16384
 
-    def _pw_x3(self, i):
-        t = self._pw_x3_cache.get(i)
+    def _pw_x3(self, i, first84=False):
+        key = (i, bool(first84))
+        t = self._pw_x3_cache.get(key)
         if t is None:
-            t = self._pw_x3_cache[i] = ops.split_bf16x3(self._pw_pad[i])
+            t = self._pw_x3_cache[key] = ops.split_bf16x3(self._pw_pad84 if first84 else self._pw_pad[i])
         return t
 
     @staticmethod
@@ -502,9 +504,9 @@ class OptFlow(_Weighted):
                 # store Mish(z) when the next consumer is another fused layer (the flow head and the
                 # split depthwise kernel take pre-activation tensors and activate on load)
                 act_out = fuse(i + 1) or (use_tail and i == 1)
-                if fp32 and self.matmul == "bf16x3" and not first84 and self._pw_pad[i].shape[0] in self.x3_filters \
+                if fp32 and self.matmul == "bf16x3" and self._pw_pad[i].shape[0] in self.x3_filters \
                         and B * H * W >= self.x3_min_pixels and ops.sepconv3x3_x3_applies(src):
-                    pw_i = self._pw_x3(i)
+                    pw_i = self._pw_x3(i, first84)
                 elif fp32:
                     pw_i = self._pw_pad84 if first84 else self._pw_pad[i]
                 else:
