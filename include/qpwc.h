@@ -331,6 +331,11 @@ int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void
 int qpwc_conv3x3s2_mish_c_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,
                               int H, int W, int C_in, void* stream);
 
+/* qpwc_conv3x3s2_mish_c_fwd for C_in in {32, 64, 128} with the products on the bf16 matrix instructions ("bf16x3",
+ * csrc/split_bf16.h): weight3 = the (9, 2 C_in, C_in) fp32 taps split by qpwc_split_bf16x3_fwd = (3, 9, 2 C_in, C_in) bf16. */
+int qpwc_conv3x3s2_mish_x3_fwd(const void* x_padded, const void* weight3, const void* bias, void* out, int B,
+                               int H, int W, int C_in, void* stream);
+
 /* The same layers for fp16 storage (BASELINE configs[4]): x_padded, weight ((9, 2 C_in, C_in)) and out fp16, bias
  * fp32, fp32 accumulation, one rounding at the store. */
 int qpwc_conv3x3s2_mish_f16_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,

@@ -85,6 +85,8 @@ int conv3x3_mish_launch(const void* x, const void* weight, const void* bias, voi
 int conv3x3_mish_x3_launch(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int C,
                            int pad_h, int pad_w, hipStream_t s);
 int split_bf16x3_launch(const void* src, void* out, int64_t n, hipStream_t s);
+int conv3x3s2_mish_x3_launch(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int CI,
+                             hipStream_t s);
 int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s);
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
@@ -667,6 +669,20 @@ int qpwc_conv3x3s2_mish_fwd(const void* x_padded, const void* weight, const void
     if (overlaps(out, (size_t)B * (H / 2) * (W / 2) * 32 * 4, x_padded, (size_t)B * (H + 1) * (W + 1) * 16 * 4))
         return fail(QPWC_E_ALIAS, "out overlaps x");
     return conv3x3s2_mish_launch(x_padded, weight, bias, out, B, H, W, (hipStream_t)stream);
+}
+
+int qpwc_conv3x3s2_mish_x3_fwd(const void* x_padded, const void* weight3, const void* bias, void* out, int B,
+                               int H, int W, int C_in, void* stream) {
+    if (!x_padded || !weight3 || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (C_in != 32 && C_in != 64 && C_in != 128) return fail(QPWC_E_SHAPE, "C_in=%d not in {32,64,128}", C_in);
+    if (B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return fail(QPWC_E_SHAPE, "B=%d H=%d W=%d: H and W must be even and >= 2", B, H, W);
+    if ((uintptr_t)x_padded % 16 || (uintptr_t)weight3 % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
+        return fail(QPWC_E_ALIGN, "x, weight3, bias, out must be 16-byte aligned");
+    if (overlaps(out, (size_t)B * (H / 2) * (W / 2) * 2 * C_in * 4, x_padded,
+                 (size_t)B * (H + 1) * (W + 1) * C_in * 4))
+        return fail(QPWC_E_ALIAS, "out overlaps x");
+    return conv3x3s2_mish_x3_launch(x_padded, weight3, bias, out, B, H, W, C_in, (hipStream_t)stream);
 }
 
 int qpwc_conv3x3s2_mish_c_fwd(const void* x_padded, const void* weight, const void* bias, void* out, int B,

@@ -333,6 +333,143 @@ int conv3x3_mish_x3_launch(const void* x, const void* w3, const void* bias, void
 }
 
 // ---------------------------------------------------------------------------
+// conv_a of encoder levels 3..5 (3x3, stride 2, TF 'SAME', bias, Mish; non_layers.py:402-409), C_in = 32 / 64 / 128 ->
+// 2 C_in, on the zero-bordered (B, H+1, W+1, C_in) input the previous level's conv_b wrote -- the bf16x3 form of
+// conv3x3s2_mish_wide_kernel: the (2 TH + 1) x 33 input patch is staged as three bf16 images, split once, in two
+// column-parity planes (pixel = ((col & 1) * IH + row) * PW + col / 2), so that the 16 output pixels of a row read 16
+// consecutive pixels for every tap; a wave = one block of 16 outputs x TH output rows, workgroup = 64 outputs,
+// grid = tiles x 2 C_in / 64; weights (3, 9, 2 C_in, C_in) bf16 streamed through a ring of nine steps as in the
+// stride-1 kernel.
+template <int CI, int TH>
+__global__ __launch_bounds__(256, (3 * 2 * (2 * TH + 1) * (kX3TW + 1) * CI * 2 > 80 * 1024) ? 1 : 2) void conv3x3s2_mish_x3_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ w3, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int CO = 2 * CI, NQ = CI / 8, NKB = CI / 32;
+    constexpr int IH = 2 * TH + 1, PW = kX3TW + 1;
+    constexpr int NPX = IH * 33, PL = 2 * IH * PW * CI;      // staged pixels; halves per image
+    constexpr int NST = (NPX * NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned short in_s[3 * PL];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int slice = blockIdx.x / n_tiles;
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kX3TW, Y0 = ty * TH;               // output coordinates
+    const int Hp = H + 1, Wp = W + 1, Ho = H / 2, Wo = W / 2;
+    const int fo = 64 * slice + 16 * wave;
+    const float* xb = x + (int64_t)b * Hp * Wp * CI;
+
+    const unsigned short* wl = w3 + (int64_t)(fo + n) * CI + 8 * g;
+    uint4 wr[9][3];
+    auto load_w = [&](uint4 (&w)[3], int kb, int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            w[p] = *reinterpret_cast<const uint4*>(wl + (int64_t)(p * 9 + tap) * CO * CI + 32 * kb);
+    };
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap) load_w(wr[tap], 0, tap);
+    {
+        float4 st[NST][2];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int pxl = idx / NQ, q = idx - pxl * NQ;
+            const int row = pxl / 33, col = pxl - row * 33;
+            const int gy = 2 * Y0 + row, gx = 2 * X0 + col;
+            const bool ok = idx < NPX * NQ && gy < Hp && gx < Wp;
+            const float* p = xb + ((int64_t)gy * Wp + gx) * CI + 8 * q;
+            st[it][0] = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st[it][1] = ok ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int pxl = idx / NQ, q = idx - pxl * NQ;
+            const int row = pxl / 33, col = pxl - row * 33;
+            const int pix = ((col & 1) * IH + row) * PW + (col >> 1);
+            if (idx < NPX * NQ) {
+                uint4 p1, p2, p3;
+                split8_bf16x3(st[it][0], st[it][1], p1, p2, p3);
+                unsigned short* d = in_s + pix * CI + 8 * x3_slot<CI>(q, pix);
+                *reinterpret_cast<uint4*>(d) = p1;
+                *reinterpret_cast<uint4*>(d + PL) = p2;
+                *reinterpret_cast<uint4*>(d + 2 * PL) = p3;
+            }
+        }
+    }
+    f32x4s acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        int nn = n, gg = g;
+        asm volatile("" : "+v"(nn), "+v"(gg));
+        uint4 bb[3][3];
+        auto read_b = [&](uint4 (&bv)[3], int i) __attribute__((always_inline)) {
+            const int tap = i / TH, m = i - tap * TH, ky = tap / 3, kx = tap - 3 * ky;
+            const int pix = ((kx & 1) * IH + 2 * m + ky) * PW + nn + (kx >> 1);
+            const unsigned short* bp = in_s + pix * CI + 8 * x3_slot<CI>(4 * kb + gg, pix);
+            bv[0] = *reinterpret_cast<const uint4*>(bp);
+            bv[1] = *reinterpret_cast<const uint4*>(bp + PL);
+            bv[2] = *reinterpret_cast<const uint4*>(bp + 2 * PL);
+        };
+        read_b(bb[0], 0);
+        read_b(bb[1], 1);
+#pragma unroll
+        for (int i = 0; i < 9 * TH; ++i) {
+            const int tap = i / TH, m = i - tap * TH;
+            if (m == 0) {
+                const int t2 = (tap + 8) % 9, kb2 = tap + 8 >= 9 ? kb + 1 : kb;
+                if (kb2 < NKB) load_w(wr[t2], kb2, t2);
+            }
+            if (i + 2 < 9 * TH) read_b(bb[(i + 2) % 3], i + 2);
+            const uint4 (&w)[3] = wr[tap];
+            const uint4 (&bv)[3] = bb[i % 3];
+            acc[m] = mfma_bf16x3(w[0], w[1], w[2], bv[0], bv[1], bv[2], acc[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* ob = out + (int64_t)b * Ho * Wo * CO;
+    const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+    for (int m = 0; m < TH; ++m) {
+        const int gy = Y0 + m, gx = X0 + n;
+        if (gy < Ho && gx < Wo)
+            *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * CO + fo + 4 * g) =
+                make_float4(x3_mishf(acc[m][0] + bq.x), x3_mishf(acc[m][1] + bq.y), x3_mishf(acc[m][2] + bq.z),
+                            x3_mishf(acc[m][3] + bq.w));
+    }
+}
+
+template <int CI, int TH>
+static int conv3x3s2_mish_x3_launch_t(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W,
+                                      hipStream_t s) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles_x = (Wo + kX3TW - 1) / kX3TW, tiles_y = (Ho + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles * (2 * CI / 64) > INT32_MAX) {
+        set_error("conv3x3s2_mish_x3: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((conv3x3s2_mish_x3_kernel<CI, TH>), dim3((unsigned)(n_tiles * (2 * CI / 64))), dim3(256), 0, s,
+                       (const float*)x, (const unsigned short*)w3, (const float*)bias, (float*)out, H, W, tiles_x, tiles_y,
+                       (int)n_tiles);
+    return check_launch("conv3x3s2_mish_x3_kernel");
+}
+
+int conv3x3s2_mish_x3_launch(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int CI,
+                             hipStream_t s) {
+    switch (CI) {
+        case 32: return conv3x3s2_mish_x3_launch_t<32, 4>(x, w3, bias, out, B, H, W, s);
+        case 64: return conv3x3s2_mish_x3_launch_t<64, 2>(x, w3, bias, out, B, H, W, s);
+        case 128: return conv3x3s2_mish_x3_launch_t<128, 2>(x, w3, bias, out, B, H, W, s);
+        default: set_error("conv3x3s2_mish_x3: C_in=%d not in {32,64,128}", CI); return QPWC_E_SHAPE;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // fp32 array -> its three bf16 images, out[p * n + i] (weights, once per model)
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ out,
                                                            int64_t n) {

@@ -274,7 +274,14 @@ class DownConv(_Weighted):
             t = self.params.get(key)
             if t is None:
                 t = self.params[key] = ops.conv3x3_taps(self.p("conv_a.weight"), padded_in.dtype)
-            after_a = ops.conv3x3s2_mish(padded_in, t, self.p32("conv_a.bias"))
+            if self.matmul == "bf16x3" and self.x3_stride2 and padded_in.dtype == torch.float32 and \
+                    padded_in.shape[3] in (32, 64, 128):
+                t3 = self.params.get(self.prefix + "#taps_a_x3")
+                if t3 is None:
+                    t3 = self.params[self.prefix + "#taps_a_x3"] = ops.split_bf16x3(t)
+                after_a = ops.conv3x3s2_mish_x3(padded_in, t3, self.p32("conv_a.bias"))
+            else:
+                after_a = ops.conv3x3s2_mish(padded_in, t, self.p32("conv_a.bias"))
         if after_a is not None:
             y = after_a.permute(0, 3, 1, 2)
         else:
@@ -314,6 +321,7 @@ class DownConv(_Weighted):
     # fp32 products of those kernels: "f32" = the fp32 matrix instructions, "bf16x3" = three-way bf16 splits of both
     # operands on the bf16 matrix instructions (csrc/split_bf16.h; error per product below one fp32 rounding)
     matmul = "f32"
+    x3_stride2 = True   # bf16x3 also for conv_a of levels 3..5 (tools/step_time.py A/B)
 
     def _hip_s2_ok(self, padded_in):
         w = self.p("conv_a.weight")

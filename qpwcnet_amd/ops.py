@@ -775,6 +775,26 @@ def conv3x3s2_mish(x_padded, taps, bias):
     return out
 
 
+def conv3x3s2_mish_x3(x_padded, taps3, bias):
+    """conv3x3s2_mish() for fp32 tensors, C_in in {32, 64, 128}, with the products on the bf16 matrix instructions
+    (qpwc_conv3x3s2_mish_x3_fwd).  taps3 = split_bf16x3(conv3x3_taps(weight)) of shape (3, 9, 2 C_in, C_in)."""
+    _check_tensor("x", x_padded)
+    ci = x_padded.shape[3]
+    if x_padded.dtype != torch.float32 or not x_padded.is_contiguous() or ci not in (32, 64, 128):
+        raise ValueError("conv3x3s2_mish_x3 needs a dense fp32 (B,H+1,W+1,C) tensor, C in {32,64,128}")
+    B, Hp, Wp, _ = x_padded.shape
+    H, W = Hp - 1, Wp - 1
+    if tuple(taps3.shape) != (3, 9, 2 * ci, ci) or taps3.dtype != torch.bfloat16 or not taps3.is_contiguous() or \
+            not taps3.is_cuda or bias.numel() != 2 * ci or bias.dtype != torch.float32:
+        raise ValueError("taps3 must be a dense (3,9,{},{}) bfloat16 device tensor, bias fp32 ({})".format(2 * ci, ci, 2 * ci))
+    out = torch.empty((B, H // 2, W // 2, 2 * ci), dtype=torch.float32, device=x_padded.device)
+    with torch.cuda.device(out.device), _timed("conv3x3s2_mish_x3", (B, H, W, ci)):
+        rc = _hip.lib().qpwc_conv3x3s2_mish_x3_fwd(x_padded.data_ptr(), taps3.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                    B, H, W, ci, _stream(out))
+    _hip.check(rc)
+    return out
+
+
 def upconv_taps(weight, dtype=torch.float32):
     """torch ConvTranspose2d weight (C_in, F, 4, 4) -> the (16, F, C_in) layout of qpwc_upconv4x4s2_mish_fwd (fp32) /
     qpwc_upconv4x4s2_mish_f16_fwd (dtype=torch.float16)."""

@@ -61,6 +61,25 @@ def test_conv3x3_mish_x3_against_float64(C, hw, pad):
         assert float(y3[:, H:].abs().max()) == 0.0 and float(y3[:, :, W:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("CI,hw", [(32, (16, 32)), (32, (22, 38)), (64, (8, 16)), (64, (14, 50)), (128, (4, 32)), (128, (10, 6))])
+def test_conv3x3s2_mish_x3_against_float64(CI, hw):
+    """conv_a of encoder levels 3..5 (stride 2, TF 'SAME' = the zero border of the padded input) in both arithmetics."""
+    rng = np.random.default_rng(CI + hw[0])
+    H, W = hw
+    xp = torch.zeros(3, H + 1, W + 1, CI)
+    xp[:, :H, :W] = _rand(rng, 3, H, W, CI) * 3
+    xp = xp.to(DEV)
+    w = (_rand(rng, 2 * CI, CI, 3, 3) / (9 * CI) ** 0.5).to(DEV)
+    b = _rand(rng, 2 * CI).to(DEV)
+    ref = F.mish(F.conv2d(xp.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=2)).permute(0, 2, 3, 1)
+    taps = ops.conv3x3_taps(w)
+    y32 = ops.conv3x3s2_mish(xp, taps, b)
+    y3 = ops.conv3x3s2_mish_x3(xp, ops.split_bf16x3(taps), b)
+    assert tuple(y3.shape) == (3, H // 2, W // 2, 2 * CI) == tuple(ref.shape)
+    e32, e3 = float((y32.double() - ref).abs().max()), float((y3.double() - ref).abs().max())
+    assert e3 < TOL and _no_worse(e3, e32, ref), (e3, e32)
+
+
 def test_conv3x3_mish_x3_rejects_bad_operands():
     x = torch.zeros(1, 8, 16, 32, device=DEV)
     taps3 = torch.zeros(3, 9, 32, 32, device=DEV, dtype=torch.bfloat16)
