@@ -349,6 +349,11 @@ int qpwc_conv3x3s2_mish_f16_fwd(const void* x_padded, const void* weight, const 
 int qpwc_upconv4x4s2_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                               int C, int F, int64_t out_pixel_stride, void* stream);
 
+/* qpwc_upconv4x4s2_mish_fwd with the products on the bf16 matrix instructions ("bf16x3", csrc/split_bf16.h):
+ * weight3 = the (16, F, C) fp32 taps split by qpwc_split_bf16x3_fwd = (3, 16, F, C) bf16; everything else as there. */
+int qpwc_upconv4x4s2_mish_x3_fwd(const void* x, const void* weight3, const void* bias, void* out, int B, int H, int W,
+                                 int C, int F, int64_t out_pixel_stride, void* stream);
+
 /* The same layer for fp16 storage (BASELINE configs[4]): x, weight ((16, F, C)) and out fp16, bias fp32, fp32
  * accumulation, one rounding at the store; out_pixel_stride in elements (halves), out 8-byte aligned. */
 int qpwc_upconv4x4s2_mish_f16_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,

@@ -87,6 +87,8 @@ int conv3x3_mish_x3_launch(const void* x, const void* w3, const void* bias, void
 int split_bf16x3_launch(const void* src, void* out, int64_t n, hipStream_t s);
 int conv3x3s2_mish_x3_launch(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int CI,
                              hipStream_t s);
+int upconv4x4s2_mish_x3_launch(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int C,
+                               int F, int out_pixel_stride, hipStream_t s);
 int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                         int C, int pad_h, int pad_w, hipStream_t s);
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
@@ -713,6 +715,21 @@ int qpwc_conv3x3s2_mish_f16_fwd(const void* x_padded, const void* weight, const 
                  (size_t)B * (H + 1) * (W + 1) * C_in * 2))
         return fail(QPWC_E_ALIAS, "out overlaps x");
     return conv3x3s2_mish_f16_launch(x_padded, weight, bias, out, B, H, W, C_in, (hipStream_t)stream);
+}
+
+int qpwc_upconv4x4s2_mish_x3_fwd(const void* x, const void* weight3, const void* bias, void* out, int B, int H, int W,
+                                 int C, int F, int64_t out_pixel_stride, void* stream) {
+    if (!x || !weight3 || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (C != 64 && C != 128 && C != 256) return fail(QPWC_E_SHAPE, "C=%d not in {64,128,256}", C);
+    if (F <= 0 || F % 16) return fail(QPWC_E_SHAPE, "F=%d must be a positive multiple of 16", F);
+    if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
+    if (out_pixel_stride < F || out_pixel_stride % 4 || out_pixel_stride > (1 << 20))
+        return fail(QPWC_E_STRIDE, "out_pixel_stride %lld must be >= F and a multiple of 4", (long long)out_pixel_stride);
+    if ((uintptr_t)x % 16 || (uintptr_t)weight3 % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
+        return fail(QPWC_E_ALIGN, "x, weight3, bias, out must be 16-byte aligned");
+    if (overlaps(out, (size_t)B * 4 * H * W * out_pixel_stride * 4, x, (size_t)B * H * W * C * 4))
+        return fail(QPWC_E_ALIAS, "out overlaps x");
+    return upconv4x4s2_mish_x3_launch(x, weight3, bias, out, B, H, W, C, F, (int)out_pixel_stride, (hipStream_t)stream);
 }
 
 int qpwc_upconv4x4s2_mish_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,

@@ -470,6 +470,116 @@ int conv3x3s2_mish_x3_launch(const void* x, const void* w3, const void* bias, vo
 }
 
 // ---------------------------------------------------------------------------
+// The decoder's UpConv (Conv2DTranspose 4x4, stride 2, 'same', bias, Mish; non_layers.py:196-210) written into the
+// `up` half of the concat([up, skip]) buffer -- the bf16x3 form of upconv4x4s2_mish_kernel: an output pixel of parity
+// (py, px) sees 2 x 2 of the 4 x 4 taps, so a wave = one parity x one block of 16 outputs x TH input rows, workgroup = the
+// four parities, grid = tiles x F / 16; the (TH + 2) x 18 halo tile of all C channels as three bf16 images; a wave's four
+// taps x 32 channels of split weights in 48 registers, the next 32-channel block's prefetched.
+// w3: (3, 16 taps, F, C) bf16.
+template <int C, int TH>
+__global__ __launch_bounds__(256, (3 * (TH + 2) * kX3HW * C * 2 > 80 * 1024) ? 1 : 2) void upconv4x4s2_mish_x3_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ w3, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int F, int out_pixel_stride, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int NH = (TH + 2) * kX3HW, PL = NH * C, NKB = C / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short in_s[3 * PL];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = wave >> 1, px = wave & 1;
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int fblk = blockIdx.x / n_tiles;
+    const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int X0 = tx * kX3TW, Y0 = ty * TH;
+    const int fo = 16 * fblk;
+    const float* xb = x + (int64_t)b * H * W * C;
+    // the 2 x 2 taps of this wave's parity: input offset (dy, dx), kernel position (ky, kx)
+    const int dy1 = py ? 1 : -1, dx1 = px ? 1 : -1;          // second tap; the first is offset 0
+    const int ky0 = py ? 2 : 1, ky1 = py ? 0 : 3, kx0 = px ? 2 : 1, kx1 = px ? 0 : 3;
+    const int kpos[4] = {ky0 * 4 + kx0, ky0 * 4 + kx1, ky1 * 4 + kx0, ky1 * 4 + kx1};
+    const int offy[4] = {0, 0, dy1, dy1}, offx[4] = {0, dx1, 0, dx1};
+    const int64_t wplane = (int64_t)16 * F * C;
+    uint4 wv[4][3], wn[4][3];
+    auto load_w = [&](uint4 (&w)[4][3], int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                w[t][p] = *reinterpret_cast<const uint4*>(w3 + p * wplane + ((int64_t)kpos[t] * F + fo + n) * C + 32 * kb + 8 * g);
+    };
+    load_w(wv, 0);
+    x3_stage_tile<C, TH>(xb, in_s, tid, Y0, X0, H, W);
+    f32x4s acc[TH];
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+        int nn = n, gg = g;
+        asm volatile("" : "+v"(nn), "+v"(gg));
+        uint4 bb[3][3];
+        auto read_b = [&](uint4 (&bv)[3], int i) __attribute__((always_inline)) {
+            const int t = i / TH, m = i - t * TH;
+            const int hp = (m + 1 + offy[t]) * kX3HW + nn + 1 + offx[t];
+            const unsigned short* bp = in_s + hp * C + 8 * x3_slot<C>(4 * kb + gg, hp);
+            bv[0] = *reinterpret_cast<const uint4*>(bp);
+            bv[1] = *reinterpret_cast<const uint4*>(bp + PL);
+            bv[2] = *reinterpret_cast<const uint4*>(bp + 2 * PL);
+        };
+        read_b(bb[0], 0);
+        read_b(bb[1], 1);
+#pragma unroll
+        for (int i = 0; i < 4 * TH; ++i) {
+            const int t = i / TH, m = i - t * TH;
+            if (i + 2 < 4 * TH) read_b(bb[(i + 2) % 3], i + 2);
+            const uint4 (&bv)[3] = bb[i % 3];
+            acc[m] = mfma_bf16x3(wv[t][0], wv[t][1], wv[t][2], bv[0], bv[1], bv[2], acc[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wv[t][p] = wn[t][p];
+    }
+    const int H2 = 2 * H, W2 = 2 * W;
+    float* ob = out + (int64_t)b * H2 * W2 * out_pixel_stride;
+    const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
+#pragma unroll
+    for (int m = 0; m < TH; ++m) {
+        const int gy = Y0 + m, gx = X0 + n;
+        if (gy < H && gx < W)
+            *reinterpret_cast<float4*>(ob + ((int64_t)(2 * gy + py) * W2 + 2 * gx + px) * out_pixel_stride + fo + 4 * g) =
+                make_float4(x3_mishf(acc[m][0] + bq.x), x3_mishf(acc[m][1] + bq.y), x3_mishf(acc[m][2] + bq.z),
+                            x3_mishf(acc[m][3] + bq.w));
+    }
+}
+
+template <int C, int TH>
+static int upconv_x3_launch_t(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int F,
+                              int out_pixel_stride, hipStream_t s) {
+    const int tiles_x = (W + kX3TW - 1) / kX3TW, tiles_y = (H + TH - 1) / TH;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
+    if (n_tiles * (F / 16) > INT32_MAX) {
+        set_error("upconv4x4s2_mish_x3: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    hipLaunchKernelGGL((upconv4x4s2_mish_x3_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), 0, s,
+                       (const float*)x, (const unsigned short*)w3, (const float*)bias, (float*)out, H, W, F,
+                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles);
+    return check_launch("upconv4x4s2_mish_x3_kernel");
+}
+
+int upconv4x4s2_mish_x3_launch(const void* x, const void* w3, const void* bias, void* out, int B, int H, int W, int C,
+                               int F, int out_pixel_stride, hipStream_t s) {
+    switch (C) {
+        case 64: return upconv_x3_launch_t<64, 8>(x, w3, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 128: return upconv_x3_launch_t<128, 4>(x, w3, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 256: return upconv_x3_launch_t<256, 2>(x, w3, bias, out, B, H, W, F, out_pixel_stride, s);
+        default: set_error("upconv4x4s2_mish_x3: C=%d not in {64,128,256}", C); return QPWC_E_SHAPE;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // fp32 array -> its three bf16 images, out[p * n + i] (weights, once per model)
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ out,
                                                            int64_t n) {

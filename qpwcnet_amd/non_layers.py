@@ -198,6 +198,12 @@ class UpConv(_Weighted):
     # (tools/skipcopy_ab.py: 1.198 vs 1.195 ms/step); round 3: the own kernel is the default, so that the only
     # library launches left on a forward are the two wide pointwise GEMMs of L0 / L1
     skip_copy_hip = True
+    matmul = "f32"      # "bf16x3": the transposed convolution's products as three-way bf16 splits (csrc/split_bf16.h)
+    # ... for the input widths where that moves the STEP (tools/step_time.py, one call, ms/step with every other bf16x3
+    # kernel on): decoder on the fp32 instructions 1.0935; all four levels split 1.0941; the three coarse levels only
+    # 1.1121 (their faster launches get in the way of the coarse flow levels they run beside, as every other change to
+    # the second queue did: DESIGN.md 7.0); the finest level (64 channels in) only 1.0829 -- that one
+    x3_channels = (64,)
 
     def _hip_upconv_ok(self, x, skip):
         w = self.p("conv_up.weight")
@@ -216,7 +222,13 @@ class UpConv(_Weighted):
             t = self.params.get(key)
             if t is None:
                 t = self.params[key] = ops.upconv_taps(self.p("conv_up.weight"), x.dtype)
-            buf = torch.empty(skip.shape[:3] + (t.shape[1] + skip.shape[3],), dtype=x.dtype, device=x.device)
+            n_up = t.shape[1]
+            if self.matmul == "bf16x3" and x.dtype == torch.float32 and x.shape[3] in self.x3_channels:
+                t3 = self.params.get(self.prefix + "#taps_up_x3")
+                if t3 is None:
+                    t3 = self.params[self.prefix + "#taps_up_x3"] = ops.split_bf16x3(t)
+                t = t3
+            buf = torch.empty(skip.shape[:3] + (n_up + skip.shape[3],), dtype=x.dtype, device=x.device)
             nch = int(hip_chunks)
             if nch > 1 and x.shape[0] % nch == 0:
                 nb = x.shape[0] // nch
@@ -224,7 +236,7 @@ class UpConv(_Weighted):
                     ops.upconv4x4s2_mish_into(x[i * nb:(i + 1) * nb], t, self.p32("conv_up.bias"), buf[i * nb:(i + 1) * nb])
             else:
                 ops.upconv4x4s2_mish_into(x, t, self.p32("conv_up.bias"), buf)
-            half = buf[..., t.shape[1]:]
+            half = buf[..., n_up:]
             if self.skip_copy_hip and ops.copy_pixels_ok(skip, half):
                 ops.copy_pixels(skip, half)     # own strided copy instead of the library's elementwise kernel
             else:

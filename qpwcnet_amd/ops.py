@@ -811,14 +811,20 @@ def upconv4x4s2_mish_into(x_nhwc, taps, bias, dst):
             not dst.is_contiguous():
         raise ValueError("upconv4x4s2_mish_into needs dense fp32 / fp16 channels-last tensors of one dtype")
     B, H, W, C = x_nhwc.shape
-    F_ = taps.shape[1]
-    if tuple(taps.shape) != (16, F_, C) or taps.dtype != x_nhwc.dtype or not taps.is_contiguous() or \
+    x3 = taps.dtype == torch.bfloat16 and taps.dim() == 4     # split_bf16x3(upconv_taps(w)): the bf16x3 arithmetic
+    F_ = taps.shape[-2]
+    if x3:
+        if tuple(taps.shape) != (3, 16, F_, C) or x_nhwc.dtype != torch.float32 or not taps.is_contiguous() or \
+                bias.numel() != F_ or bias.dtype != torch.float32:
+            raise ValueError("split taps must be (3,16,F,{}) bfloat16 with fp32 tensors, bias fp32 (F)".format(C))
+    elif tuple(taps.shape) != (16, F_, C) or taps.dtype != x_nhwc.dtype or not taps.is_contiguous() or \
             bias.numel() != F_ or bias.dtype != torch.float32:
         raise ValueError("taps must be (16,F,{}) of the input's dtype, bias fp32 (F)".format(C))
     if tuple(dst.shape[:3]) != (B, 2 * H, 2 * W) or dst.shape[3] < F_:
         raise ValueError("dst must be (B,2H,2W,Ctot) with Ctot >= F")
     f16 = x_nhwc.dtype == torch.float16
-    fn = _hip.lib().qpwc_upconv4x4s2_mish_f16_fwd if f16 else _hip.lib().qpwc_upconv4x4s2_mish_fwd
+    fn = _hip.lib().qpwc_upconv4x4s2_mish_x3_fwd if x3 else (
+        _hip.lib().qpwc_upconv4x4s2_mish_f16_fwd if f16 else _hip.lib().qpwc_upconv4x4s2_mish_fwd)
     with torch.cuda.device(dst.device), _timed("upconv4x4s2_mish_f16" if f16 else "upconv4x4s2_mish", (B, H, W, C, F_)):
         rc = fn(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(), dst.data_ptr(), B, H, W, C, F_, dst.shape[3],
                 _stream(dst))

@@ -80,6 +80,29 @@ def test_conv3x3s2_mish_x3_against_float64(CI, hw):
     assert e3 < TOL and _no_worse(e3, e32, ref), (e3, e32)
 
 
+@pytest.mark.parametrize("C,Fo,hw", [(64, 16, (16, 32)), (64, 32, (11, 19)), (128, 32, (8, 16)), (128, 64, (5, 21)),
+                                      (256, 64, (4, 16)), (256, 128, (3, 5))])
+def test_upconv4x4s2_mish_x3_against_float64(C, Fo, hw):
+    """The decoder's UpConv (Conv2DTranspose 4x4, stride 2, 'same', bias, Mish) written into the concat buffer, in both
+    arithmetics; the skip half of the buffer stays untouched."""
+    rng = np.random.default_rng(C + Fo + hw[0])
+    H, W = hw
+    x = (_rand(rng, 2, H, W, C) * 2).to(DEV)
+    w = (_rand(rng, C, Fo, 4, 4) / (4 * C) ** 0.5).to(DEV)
+    b = _rand(rng, Fo).to(DEV)
+    ref = F.mish(F.conv_transpose2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=2, padding=1)
+                 ).permute(0, 2, 3, 1)
+    taps = ops.upconv_taps(w)
+    d32 = torch.full((2, 2 * H, 2 * W, Fo + 8), 7.0, device=DEV)
+    d3 = torch.full((2, 2 * H, 2 * W, Fo + 8), 7.0, device=DEV)
+    ops.upconv4x4s2_mish_into(x, taps, b, d32)
+    ops.upconv4x4s2_mish_into(x, ops.split_bf16x3(taps), b, d3)
+    assert bool((d3[..., Fo:] == 7.0).all())
+    e32 = float((d32[..., :Fo].double() - ref).abs().max())
+    e3 = float((d3[..., :Fo].double() - ref).abs().max())
+    assert e3 < TOL and _no_worse(e3, e32, ref), (e3, e32)
+
+
 def test_conv3x3_mish_x3_rejects_bad_operands():
     x = torch.zeros(1, 8, 16, 32, device=DEV)
     taps3 = torch.zeros(3, 9, 32, 32, device=DEV, dtype=torch.bfloat16)
