@@ -77,8 +77,8 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 // runs): stride-1 layers C = 64 / 128 / 256: 33.3 / 30.4 / 33.2 -> 29.7 / 29.7 / 30.1 us (two steps ahead: 32.0 / 29.4 /
 // 30.2), step 1.2006 -> 1.1826 ms -- kept (QPWC_ENC_PIPE = 1).  The stride-2 layers do not move (17.4-20.6 us either
 // way, step 1.1816 vs 1.1809) and the decoder's transposed convolution gets 7 us SLOWER per step with it (1.1886 vs
-// 1.1816: on the second queue, beside the coarse flow levels, see QpwcNet.dec_chunks) -- both stay as the compiler
-// schedules them.
+// 1.1816: on the second queue, beside the coarse flow levels, see QpwcNet.dec_chunks; on the finest decoder level only,
+// QPWC_UPCONV_PIPE = 2: 1.1758 vs 1.1780, inside the noise) -- both stay as the compiler schedules them.
 #ifndef QPWC_ENC16_PIPE
 #define QPWC_ENC16_PIPE 1   // the fp16 wide kernel: a tap's operand reads one tap ahead (0 = as the compiler places them)
 #endif
@@ -873,7 +873,8 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
 #pragma unroll 1
     for (int kb = 0; kb < NKB; ++kb) {
         if (kb + 1 < NKB) load_w(wn, kb + 1);
-#if QPWC_UPCONV_PIPE
+        // QPWC_UPCONV_PIPE: 1 = every level, 2 = the finest decoder level (C = 64) only
+        if constexpr (QPWC_UPCONV_PIPE == 1 || (QPWC_UPCONV_PIPE == 2 && C == 64)) {
         // one step = (tap, 16-channel chunk); the operand reads of step i + 1 go out before the matrix instructions of
         // step i (as in conv3x3_mish_wide_kernel)
         f32x4e bb[2][TH];
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i >> 1][i & 1][j], bb[i & 1][m][j], acc[m], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-#else
+        } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
                     for (int m = 0; m < TH; ++m)
                         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][kc][j], bv[m][j], acc[m], 0, 0, 0);
             }
-#endif
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
