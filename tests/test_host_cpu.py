@@ -335,7 +335,8 @@ def test_bench_line_fits_the_drivers_window():
                 per_level_epe_vs_oracle=[2.69e-07] * 6, per_level_epe_vs_ground_truth=[1.0] * 6,
                 serving_throughput={"value": 7232.9, "batches_in_flight": 2, "note": "n" * 100},
                 matmul_bf16x3={"value": 6967.123456, "unit": "pairs/s", "ms_per_step": 1.14823456,
-                               "max_abs_flow_diff_vs_headline_px": 1.3113e-06, "note": "n" * 200},
+                               "max_abs_flow_diff_vs_headline_px": 1.3113e-06,
+                               "mean_abs_flow_diff_vs_headline_px": 1.8912e-07, "note": "n" * 200},
                 library={"path": "/p", "version": 200, "build": "libqpwc_hip gfx950 product (no environment switches)",
                          "product": True},
                 detail_file="bench_detail.json",
