@@ -59,6 +59,10 @@ def parse_args(argv=None):
     p.add_argument("--inflight", type=int, default=2, help="batches in flight of the serving_throughput leg")
     p.add_argument("--no-inflight", action="store_true",
                    help="skip the extra '2 batches in flight' throughput measurement (N=1 only)")
+    p.add_argument("--matmul", default="f32", choices=["f32", "bf16x3"],
+                   help="arithmetic of the fp32 convolution products: f32 = the fp32 matrix instructions (the line's "
+                        "default and the only form reported as the headline); bf16x3 = three-way bf16 splits "
+                        "(DESIGN.md 4.11) -- the run is then labelled so in config.matmul (profiling / A-B runs)")
     p.add_argument("--no-extra", action="store_true",
                    help="skip the extra_configs legs (BASELINE configs[3] and configs[4]; N=1 default run only)")
     p.add_argument("--dtype", default="f32", choices=["f32", "f16"],
@@ -427,6 +431,8 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
                          dtype=tdtype)
     if args.no_overlap:
         model.overlap_streams = False
+    if args.matmul != "f32" and dtype == "f32":
+        model.matmul = args.matmul
     pairs_np, gt_np = synth.make_frames(B, hw[0], hw[1], seed=1234 + rank)
     pairs_cl = torch.from_numpy(pairs_np).to(dev, tdtype)
     pairs = pairs_cl if cl else pairs_cl.permute(0, 3, 1, 2).contiguous()
@@ -516,6 +522,7 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
                                                     synth.level_channels()[i + 1]), tdtype)))
                              for i, u in enumerate(model.upflows)],
             "hip_optflow": True,
+            "matmul": model.matmul,
             "weights": "seeded glorot (synth.make_weights(42)), 3.09M params",
         },
         "per_level_epe_vs_ground_truth": [float(x) for x in epe_mean.cpu()],
@@ -556,7 +563,8 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
     # ---- the same step with the fp32 matrix products as three-way bf16 splits on the bf16 matrix instructions
     # (QpwcNet.matmul = "bf16x3", csrc/split_bf16.h): reported BESIDE the headline, which stays on the fp32 matrix
     # instructions; same inputs, same K steps, flows compared with the headline's
-    if headline and graphs is not None and world == 1 and dtype == "f32" and not args.no_inflight:
+    if headline and graphs is not None and world == 1 and dtype == "f32" and not args.no_inflight and \
+            args.matmul == "f32":
         ref_flows = [f.clone() for f in graphs[0].outputs]
         model.matmul = "bf16x3"
         try:
@@ -634,6 +642,8 @@ def compact_line(full):
     c = full["config"]
     line["config"] = {k: c[k] for k in ("workload", "global_batch", "batch_per_gpu", "parallelism", "hipgraph",
                                         "fused_upflow") if k in c}
+    if c.get("matmul", "f32") != "f32":     # an explicitly requested arithmetic is named in the line
+        line["config"]["matmul"] = c["matmul"]
     line["roofline"] = compact_roofline(full["roofline"])
     cb = full.get("cpu_baseline")
     if cb:
@@ -739,7 +749,7 @@ def main():
                                                  world, rank, dev, True, copy_gbs)
     result["library"] = info
     default_run = (world == 1 and args.batch == 8 and hw == (256, 512) and args.dtype == "f32" and
-                   args.data_format == "channels_last" and not args.no_graph)
+                   args.data_format == "channels_last" and not args.no_graph and args.matmul == "f32")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             base, epe_oracle = cpu_baseline(weights, pairs_np, args.cpu_pairs, args.cpu_reps, flows, hw)
