@@ -287,14 +287,15 @@ int qpwc_conv3x3_mish_fwd(const void* x, const void* weight, const void* bias, v
                           int W, int C, int pad_h, int pad_w, void* stream);
 
 /* The same fp32 layer with its products on the bf16 matrix instructions ("bf16x3", csrc/split_bf16.h): both
- * operands are split into three bf16 values, six partial products per product, fp32 accumulation -- the error per
- * product is below one fp32 rounding.  x, bias, out as qpwc_conv3x3_mish_fwd; weight3: the (9, C, C) fp32 taps split
+ * operands are split (exactly) into three bf16 values, six partial products per product, fp32 accumulation -- what is
+ * dropped per product is about one fp32 rounding at worst (2^-23), 2^-28 on average.  x, bias, out as qpwc_conv3x3_mish_fwd; weight3: the (9, C, C) fp32 taps split
  * by qpwc_split_bf16x3_fwd = (3, 9, C, C) bf16. */
 int qpwc_conv3x3_mish_x3_fwd(const void* x, const void* weight3, const void* bias, void* out, int B, int H,
                              int W, int C, int pad_h, int pad_w, void* stream);
 
 /* src (n) fp32 -> out (3, n) bf16: out[0] = bf16(src), out[1] = bf16(src - out[0]), out[2] = bf16(src - out[0] -
- * out[1]), round to nearest even; src[i] == out[0][i] + out[1][i] + out[2][i] to within 2^-27 |src[i]|.
+ * out[1]), round to nearest even; src[i] == out[0][i] + out[1][i] + out[2][i] exactly (parts below the smallest normal
+ * fp32 flush to zero).
  * The weight operands of the *_x3_fwd entry points. */
 int qpwc_split_bf16x3_fwd(const void* src, void* out, long long n, void* stream);
 

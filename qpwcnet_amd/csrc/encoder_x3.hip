@@ -1,6 +1,6 @@
 // The encoder's 3x3 stride-1 'same' convolution + bias + Mish (conv_aa / conv_b, qpwcnet/core/non_layers.py:410-449
 // with use_normalizer=False, pwcnet.py:146), fp32 in and out, with the products on the bf16 matrix instructions as
-// three-way splits of both operands (split_bf16.h: six partial products, error below an fp32 rounding per product).
+// three-way splits of both operands (split_bf16.h: six partial products, about one fp32 rounding per product at worst, 2^-28 on average).
 // The fp32-instruction kernels of encoder.hip run these layers at 70-82 TF (0.45-0.5 of the fp32 matrix peak); here
 // the matrix work of a layer (2.4 GFLOP x 6 partial products) is 7-8 us of the bf16 pipe and the layer is bound by
 // staging and its activations' bytes instead.

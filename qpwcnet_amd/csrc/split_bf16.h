@@ -2,16 +2,18 @@
 // (v_mfma_f32_16x16x4_f32, 32 cycles for 2 kFLOP) run at 1/16 of the bf16 rate (v_mfma_f32_16x16x32_bf16, 16 cycles
 // for 16 kFLOP), so an fp32 convolution is bound by them at 0.4-0.5 of a 157 TF peak while the activations' bytes
 // would allow 3-4 x more.  Every fp32 value is split into three bf16 values,
-//     a = a1 + a2 + a3,   a1 = bf16(a),  a2 = bf16(a - a1),  a3 = bf16(a - a1 - a2)   (round to nearest even),
-// |a2| <= 2^-9 |a|, |a3| <= 2^-18 |a|, residual <= 2^-27 |a| (the two subtractions are exact in fp32), and a
-// product a * b is the sum of the six partial products
+//     a = a1 + a2 + a3,   a1 = bf16(a),  a2 = bf16(a - a1),  a3 = bf16(a - a1 - a2)   (round to nearest even).
+// The split is EXACT: the two subtractions are exact in fp32, |a2| <= 2^-8 |a|, and what is left after a2 is a multiple
+// of a's last bit below 2^-16 |a| -- at most 8 significant bits, a bf16 value (|a3| <= 2^-16 |a|; 2^-17 measured).
+// A product a * b is the sum of the six partial products
 //     a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2)
-// -- each exact in fp32 (8 x 8 significant bits), accumulated in fp32 by the matrix instruction.  What is dropped
-// (a2 b3 + a3 b2 + a3 b3 and the split residuals) is below 2^-25 |a b|: less than the 2^-24 rounding of the product
-// an fp32 multiply-add itself commits.  Six bf16 instructions of 16 cycles replace eight fp32 instructions of 32
-// cycles for the same 32-deep slice of the reduction (96 vs 256 cycles).  bf16 has fp32's exponent range, so the
-// split needs no scaling; a3 (and a2 for |a| < 2^-109) may flush to zero near the bottom of the fp32 range, where
-// the absolute error is < 2^-126.
+// -- each exact in fp32 (8 x 8 significant bits), accumulated in fp32 by the matrix instruction.  What is dropped is
+// a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b| in the worst case; over 4 M random pairs (tests/test_host_cpu.py restates the
+// arithmetic with torch's bfloat16) the six-term sum is off by 2^-24.2 at most and 2^-28.1 on average -- below what ONE
+// fp32 rounding costs (2^-24 at most, 2^-25.5 on average), and every accumulation step of either arithmetic commits
+// such a rounding of the running sum.  Six bf16 instructions of 16 cycles replace eight fp32 instructions of 32 cycles for
+// the same 32-deep slice of the reduction (96 vs 256 cycles).  bf16 has fp32's exponent range, so the split needs no
+// scaling; parts below the smallest normal fp32 flush to zero (absolute error < 2^-126 there).
 // tests/test_gpu_x3.py compares both arithmetic forms with float64 on the same inputs.
 #pragma once
 #include <hip/hip_runtime.h>

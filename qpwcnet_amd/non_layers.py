@@ -331,7 +331,7 @@ class DownConv(_Weighted):
     # 64 / 128 / 256 with a wave per 16-output block) instead of library convolution + bias/Mish pass
     hip_conv = True
     # fp32 products of those kernels: "f32" = the fp32 matrix instructions, "bf16x3" = three-way bf16 splits of both
-    # operands on the bf16 matrix instructions (csrc/split_bf16.h; error per product below one fp32 rounding)
+    # operands on the bf16 matrix instructions (csrc/split_bf16.h; error per product about one fp32 rounding at worst, 2^-28 on average)
     matmul = "f32"
     x3_stride2 = True   # bf16x3 also for conv_a of levels 3..5 (tools/step_time.py A/B)
 

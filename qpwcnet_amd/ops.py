@@ -690,7 +690,7 @@ def conv3x3_mish(x_nhwc, taps, bias, pad_h=0, pad_w=0):
 
 def split_bf16x3(t):
     """fp32 device tensor -> (3, *t.shape) bfloat16: the three-way split of csrc/split_bf16.h (qpwc_split_bf16x3_fwd);
-    out[0] + out[1] + out[2] == t to within 2^-27 |t|.  The weight operands of the *_x3 kernels."""
+    out[0] + out[1] + out[2] == t exactly (parts below the smallest normal fp32 flush to zero).  The weight operands of the *_x3 kernels."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.numel() == 0:
         raise ValueError("split_bf16x3 takes a non-empty fp32 device tensor")
     t = t.contiguous()

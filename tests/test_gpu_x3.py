@@ -26,7 +26,7 @@ def _no_worse(e_x3, e_f32, ref):
     return e_x3 <= 2.0 * e_f32 + 2.0 ** -23 * float(ref.abs().max())
 
 
-def test_split_is_exact_to_27_bits():
+def test_split_is_exact():
     rng = np.random.default_rng(0)
     x = _rand(rng, 1 << 16)
     x = torch.cat([x, x * 1e30, x * 1e-30, torch.tensor([0.0, -0.0, 1.0, -1.0, 3.3895314e38, 1e-35, 65504.0])])
@@ -34,8 +34,11 @@ def test_split_is_exact_to_27_bits():
     assert parts.dtype == torch.bfloat16 and tuple(parts.shape) == (3, x.numel())
     back = parts.double().sum(0).cpu()
     err = (back - x.double()).abs()
-    # (parts below the smallest normal fp32 flush to zero: absolute error < 2^-126 there, split_bf16.h)
-    assert bool((err <= 2.0 ** -26 * x.double().abs() + 2.0 ** -126).all()), float((err / x.double().abs().clamp_min(1e-300)).max())
+    # exact wherever all three parts are normal numbers; parts below the smallest normal fp32 flush to zero (absolute
+    # error < 2^-126 there, split_bf16.h)
+    big = x.double().abs() >= 1e-25
+    assert bool((err[big] == 0).all()), float((err[big] / x.double().abs()[big]).max())
+    assert bool((err <= 2.0 ** -126).all())
     # the first part is plain round-to-nearest-even bf16
     assert torch.equal(parts[0].cpu(), x.to(torch.bfloat16))
 
