@@ -47,10 +47,19 @@ __device__ __forceinline__ void split8_bf16x3(const float4& lo, const float4& hi
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
+#ifndef QPWC_X3_TERMS
+#define QPWC_X3_TERMS 6
+#endif
+
 // acc += A * B for one 32-deep slice: A = (a1, a2, a3), B = (b1, b2, b3) as split above; smallest terms first
 __device__ __forceinline__ f32x4s mfma_bf16x3(const uint4& a1, const uint4& a2, const uint4& a3, const uint4& b1,
                                               const uint4& b2, const uint4& b3, f32x4s acc) {
 #define QPWC_X3_MFMA(A, B) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8e, A), __builtin_bit_cast(bf16x8e, B), acc, 0, 0, 0)
+#if QPWC_X3_TERMS == 9   // all nine partial products: every product exact (A/B build; 144 instead of 96 cycles per slice)
+    QPWC_X3_MFMA(a3, b3);
+    QPWC_X3_MFMA(a3, b2);
+    QPWC_X3_MFMA(a2, b3);
+#endif
     QPWC_X3_MFMA(a2, b2);
     QPWC_X3_MFMA(a3, b1);
     QPWC_X3_MFMA(a1, b3);
