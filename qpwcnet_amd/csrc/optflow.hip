@@ -1471,6 +1471,16 @@ int bias_mish_launch(void* x, const void* bias, int64_t n_pixels, int C, int dty
 // ---------------------------------------------------------------------------
 // Upsample(scale): scale * UpSampling2D(2, 'bilinear') of a flow field (B,h,w,2)
 // (non_layers.py:183-193; half-pixel centres, edge-clamped: src = max(0, (dst+.5)/2 - .5)).
+// scale * (w00 v00 + w01 v01 + w10 v10 + w11 v11) as ONE explicit chain of fused multiply-adds: both upsampling kernels
+// call it, so that they agree bit for bit whatever the compiler would contract on its own
+__device__ __forceinline__ float2 bilerp_flow(float ly, float lx, float2 v00, float2 v01, float2 v10, float2 v11, float scale) {
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    float2 r;
+    r.x = scale * fmaf(w11, v11.x, fmaf(w10, v10.x, fmaf(w01, v01.x, w00 * v00.x)));
+    r.y = scale * fmaf(w11, v11.y, fmaf(w10, v10.y, fmaf(w01, v01.y, w00 * v00.y)));
+    return r;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restrict__ in,
                                                               T* __restrict__ out, int B, int h,
@@ -1497,10 +1507,7 @@ __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restric
             return make_float2(ld(q), ld(q + 1));
         };
         const float2 v00 = px(y0, x0), v01 = px(y0, x1), v10 = px(y1, x0), v11 = px(y1, x1);
-        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-        float2 r;
-        r.x = scale * (w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x);
-        r.y = scale * (w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y);
+        const float2 r = bilerp_flow(ly, lx, v00, v01, v10, v11, scale);
         if (out_nchw) {
             T* o = out + ((int64_t)(b * 2) * H + y) * W + x;
             st(o, r.x);
@@ -1512,9 +1519,74 @@ __global__ __launch_bounds__(256) void upsample2x_flow_kernel(const T* __restric
     }
 }
 
+// Channels-last in and out (every call of the channels_last network): a thread owns TWO horizontally adjacent output
+// pixels -- the arithmetic of the kernel above (bilerp_flow: bit-identical results), with each input
+// pixel read as one 8- / 4-byte vector and the pair written as one 16- / 8-byte store, 32-bit indices
+// (round 3: step 1.1749 -> 1.1703 ms, config 5's 1.6226 -> 1.6115 ms).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_flow_pair_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                                   int n_pairs, int h, int w, float scale) {
+    QPWC_FLOW_CHAIN_PRIO();
+    const int H = 2 * h;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n_pairs; idx += gridDim.x * 256) {
+        const int j = idx % w;
+        const int t = idx / w;
+        const int y = t % H, b = t / H;
+        const float sy = fmaxf(0.0f, (y + 0.5f) * 0.5f - 0.5f);
+        const int y0 = (int)sy;
+        const int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+        const float ly = sy - y0;
+        const T* p = in + (int64_t)b * h * w * 2;
+        auto px = [&](int yy, int xx) __attribute__((always_inline)) {
+            if constexpr (sizeof(T) == 4) {
+                return *reinterpret_cast<const float2*>(p + (yy * w + xx) * 2);
+            } else {
+                return __half22float2(*reinterpret_cast<const __half2*>(p + (yy * w + xx) * 2));
+            }
+        };
+        float2 r[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int x = 2 * j + e;
+            const float sx = fmaxf(0.0f, (x + 0.5f) * 0.5f - 0.5f);
+            const int x0 = (int)sx;
+            const int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+            const float lx = sx - x0;
+            const float2 v00 = px(y0, x0), v01 = px(y0, x1), v10 = px(y1, x0), v11 = px(y1, x1);
+            r[e] = bilerp_flow(ly, lx, v00, v01, v10, v11, scale);
+        }
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(out + (int64_t)idx * 4) = make_float4(r[0].x, r[0].y, r[1].x, r[1].y);
+        } else {
+            const __half2 a = __floats2half2_rn(r[0].x, r[0].y), c = __floats2half2_rn(r[1].x, r[1].y);
+            uint2 u;
+            u.x = *reinterpret_cast<const unsigned*>(&a);
+            u.y = *reinterpret_cast<const unsigned*>(&c);
+            *reinterpret_cast<uint2*>(out + (int64_t)idx * 4) = u;
+        }
+    }
+}
+
+#ifndef QPWC_UPSAMPLE_PAIRS
+#define QPWC_UPSAMPLE_PAIRS 1   // 0: every call on the one-pixel-per-thread kernel (A/B)
+#endif
 int upsample2x_flow_launch(const void* in, void* out, int B, int h, int w, float scale, int dtype,
                            int in_layout, int out_layout, hipStream_t s) {
     const int in_nchw = in_layout == QPWC_NCHW, out_nchw = out_layout == QPWC_NCHW;
+    const int64_t n_pairs = (int64_t)B * 2 * h * w;
+    const size_t es = dtype == QPWC_F32 ? 4 : 2;
+    if (QPWC_UPSAMPLE_PAIRS && !in_nchw && !out_nchw && n_pairs * 4 < INT32_MAX &&
+        reinterpret_cast<uintptr_t>(in) % (2 * es) == 0 && reinterpret_cast<uintptr_t>(out) % (4 * es) == 0) {
+        const int64_t wantp = (n_pairs + 255) / 256;
+        const dim3 gridp((unsigned)(wantp < 16384 ? wantp : 16384));
+        if (dtype == QPWC_F32)
+            hipLaunchKernelGGL(upsample2x_flow_pair_kernel<float>, gridp, dim3(256), 0, s, (const float*)in, (float*)out,
+                               (int)n_pairs, h, w, scale);
+        else
+            hipLaunchKernelGGL(upsample2x_flow_pair_kernel<__half>, gridp, dim3(256), 0, s, (const __half*)in,
+                               (__half*)out, (int)n_pairs, h, w, scale);
+        return check_launch("upsample2x_flow_pair_kernel");
+    }
     const int64_t total = (int64_t)B * 4 * h * w;
     const int64_t want = (total + 255) / 256;
     const dim3 grid((unsigned)(want < 8192 ? want : 8192));

@@ -126,6 +126,20 @@ def test_upsample2x_flow(hw):
     torch.testing.assert_close(out2, ref, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+@pytest.mark.parametrize("hw", [(1, 1), (1, 5), (7, 1), (9, 13), (64, 128)])
+def test_upsample2x_flow_pair_kernel_equals_the_pixel_kernel(hw, dtype):
+    """Channels-last calls take the two-pixels-per-thread kernel (vector loads, one 16- / 8-byte store per pair); the
+    channels_first layout still runs the one-pixel kernel: same expressions, so the two must agree bit for bit."""
+    rng = np.random.default_rng(hw[0] * 31 + hw[1])
+    f = torch.from_numpy(rng.standard_normal((3, hw[0], hw[1], 2)).astype(np.float32)).to(DEV, dtype)
+    pair = ops.upsample2x_flow(f, 2.0)
+    pixel = ops.upsample2x_flow(f.permute(0, 3, 1, 2).contiguous(), 2.0, in_format="channels_first",
+                                out_format="channels_first")
+    assert tuple(pair.shape) == (3, 2 * hw[0], 2 * hw[1], 2)
+    assert torch.equal(pair, pixel.permute(0, 2, 3, 1))
+
+
 def test_optflow_pieces_fp16_storage():
     """fp16 storage / fp32 arithmetic variants of the OptFlow kernels (BASELINE configs[4]);
     bound: the fp32 oracle on the fp16-rounded inputs, output rounding only."""
