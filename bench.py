@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s 
 HBM_GUIDE_COPY_GBS = 6290.0
 F32_MFMA_PEAK_TFS = 157.3  # dense fp32 matrix peak (same guide)
 F16_MFMA_PEAK_TFS = 2500.0  # dense fp16/bf16 matrix peak
+PARITY_TOL_PX = 1e-4       # north_star: "outputs matching the TF2 reference within 1e-4 fp32"; the run FAILS above it
 
 
 def parse_args(argv=None):
@@ -46,6 +47,9 @@ def parse_args(argv=None):
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--batch", type=int, default=8, help="pairs per GPU (weak scaling)")
+    p.add_argument("--global-batch", type=int, default=0,
+                   help="STRONG scaling: this many pairs in total, sharded over the ranks by dist.shard_range "
+                        "(BASELINE configs[2] literally: --gpus 8 --global-batch 64); 0 = --batch pairs per GPU")
     p.add_argument("--height", type=int, default=256)
     p.add_argument("--width", type=int, default=512)
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -95,7 +99,11 @@ class _Operand:
         return len(self.shape)
 
 
-def baseline_config_name(B, hw, dtype, world):
+def baseline_config_name(B, hw, dtype, world, global_batch=0):
+    if global_batch:
+        if hw == (256, 512) and dtype == "f32" and global_batch == 64 and world == 8:
+            return "BASELINE configs[2] (64 pairs sharded over 8 GPUs, strong scaling)"
+        return "non-BASELINE workload ({} pairs sharded over {} GPUs, strong scaling)".format(global_batch, world)
     if hw == (256, 512) and dtype == "f32" and B == 8:
         return "BASELINE configs[1]" if world == 1 else (
             "BASELINE configs[2]" if world == 8 else "BASELINE configs[1] per GPU on {} GPUs".format(world))
@@ -132,27 +140,14 @@ def sepconv_flops(B, H, W, C, F):
 
 
 def cost_volume_symbol(B, H, W, C, dtype):
-    """The kernel symbol qpwc_cost_volume_fwd selects for an NHWC r=4 launch -- the same eligibility rule
-    as cost_volume_mfma_launch (csrc/cost_volume_mfma.hip)."""
-    if C % 16:
-        return "cost_volume_tiled_kernel"
-    regions = ((W + 7) // 8) * ((H + 7) // 8) * B
-    if C % 32 == 0 and regions >= 256:
-        return "cost_volume_mfma_lds_kernel" if dtype == "f32" else "cost_volume_mfma_lds_f16_kernel"
-    return "cost_volume_mfma_kernel"
+    """The kernel qpwc_cost_volume_fwd launches for an NHWC r=4 shape: asked of the library's own selection rules
+    (qpwc_cost_volume_kernel, a dry run of the launchers -- host only), never a copy of them."""
+    return ops.cost_volume_kernel(B, H, W, C, dtype, fused=False)
 
 
-def fused_front_symbol(B, H, W, C, dtype):
-    """The kernel symbol qpwc_warp_cost_volume_fwd selects where the matrix-core fused kernel applies -- the rules of
-    launch_lds (csrc/cost_volume_mfma.hip): fp32 from two 32-channel steps on: 16 x 16 regions (>= 256 of them); one
-    step: 8 x 16 regions (>= 512); else the 8 x 8 kernel."""
-    if dtype != "f32":
-        return "cost_volume_mfma_lds_f16_kernel<true>"
-    if C >= 64 and ((W + 15) // 16) * ((H + 15) // 16) * B >= 256:
-        return "cost_volume_mfma_lds16_kernel<true>"
-    if C == 32 and ((W + 15) // 16) * ((H + 7) // 8) * B >= 512:
-        return "cost_volume_mfma_lds8x16_warp_kernel"
-    return "cost_volume_mfma_lds_kernel<true>"
+def fused_front_symbol(B, H, W, C, dtype, out_pixel_stride=0):
+    """The kernel qpwc_warp_cost_volume_fwd launches for this shape (same query)."""
+    return ops.cost_volume_kernel(B, H, W, C, dtype, fused=True, out_pixel_stride=out_pixel_stride)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -370,10 +365,9 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
         unf = cost_volume_bytes(*lvl4, esize) + warp_bytes(*lvl4, esize)
         fb = fused_front_bytes(*lvl4, esize)
         in_step = ktimes.get(key_fcv)
-        mfma_fused = non_layers.fused_kernel_applies(prv)
         out["warp_cost_volume_fused"] = hbm_block(
             "fused WarpV2+cost volume L4 {}".format("x".join(map(str, lvl4))),
-            fused_front_symbol(*lvl4, dtype) if mfma_fused else "cost_volume_tiled_kernel<fused>",
+            fused_front_symbol(*lvl4, dtype, stride),
             unf, f_ms, "warp_cost_volume_L4_bytes_per_launch",
             {"used_by_the_step_at_L4": fused4, "unfused_pair_ms": cv_ms + w_ms,
              "algorithmic_bytes_basis": "unfused pair: cost volume B*H*W*(2C+81)*e + warp B*H*W*(2C+2)*e (SURVEY 8(d))",
@@ -422,8 +416,9 @@ def rooflines(model, model_input, B, hw, dtype, tdtype, dev, args, copy_gbs):
     return out, hot
 
 
-def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_gbs):
-    """One configuration end to end -> the fields of its JSON object."""
+def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_gbs, global_batch=0):
+    """One configuration end to end -> the fields of its JSON object.  global_batch > 0: B is this rank's shard of
+    that many pairs (strong scaling); otherwise every rank runs B pairs (weak scaling)."""
     tdtype = torch.float32 if dtype == "f32" else torch.float16
     weights = synth.make_weights(42, hw)
     cl = args.data_format == "channels_last"
@@ -497,21 +492,29 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
     elapsed, results = qdist.timed_steps(run_step, gather, steps, warmup, dev)
     per_rank, epe_mean = results[-1]
     assert len(results) == steps
+    total_pairs = global_batch if global_batch else world * B
+    if tuple(per_rank.shape) != (world, 6):
+        raise RuntimeError("all-gather of the per-level EPE returned {} for {} ranks".format(tuple(per_rank.shape), world))
 
     res = {
         "metric": metric_name(hw, dtype),
-        "value": world * B * steps / elapsed,
+        "value": total_pairs * steps / elapsed,
         "unit": "pairs/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if global_batch else "weak", "vs_baseline": None,
+        # what the one collective of the path saw in the LAST timed step: one row per rank, one column per level
+        "allgather": {"ranks_in_allgather": int(per_rank.shape[0]), "levels_per_rank": int(per_rank.shape[1]),
+                      "backend": "none (single process)" if world == 1 and not gather.collective else
+                                 ("gloo" if gloo else "nccl (RCCL)"),
+                      "finest_level_epe_per_rank": [float(x) for x in per_rank[:, -1].cpu()]},
         "dtype": dtype, "data": "synthetic",
         "config": {
             "workload": "{}: full 6-level PWC-Net (qpwcnet build_flower) inference, batch {} per GPU, "
                         "{}x{} {}, {}, d=4 cost volume + WarpV2".format(
-                            baseline_config_name(B, hw, dtype, world), B, hw[0], hw[1],
+                            baseline_config_name(B, hw, dtype, world, global_batch), B, hw[0], hw[1],
                             "fp32" if dtype == "f32" else "fp16 storage (fp32 accumulate)", args.data_format),
-            "global_batch": world * B, "batch_per_gpu": B,
+            "global_batch": total_pairs, "batch_per_gpu": B,
             "parallelism": "dp{} (pairs sharded, {} all-gather of the 6 per-level EPE)".format(
                 world, "gloo REHEARSAL on one GPU:" if gloo else "RCCL"),
             "hipgraph": graphs is not None,
@@ -586,6 +589,9 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
                 "note": "opt-in arithmetic (encoder 3x3 convolutions and the 64-output SeparableConv2D layers): six bf16 "
                         "partial products per fp32 product, fp32 accumulate; not the headline value"}
             del gx
+        except Exception as e:  # noqa: BLE001 -- an opt-in side leg must never lose the headline line
+            res["matmul_bf16x3"] = {"error": str(e).splitlines()[0][:160] if str(e) else type(e).__name__}
+            torch.cuda.synchronize()
         finally:
             model.matmul = "f32"
         del ref_flows
@@ -639,6 +645,10 @@ def compact_line(full):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data")
     line = {k: _r(full[k], 7) for k in keep}
+    if "allgather" in full:
+        ag = full["allgather"]
+        line["allgather"] = {"ranks_in_allgather": ag["ranks_in_allgather"], "levels_per_rank": ag["levels_per_rank"],
+                             "backend": ag["backend"]}
     c = full["config"]
     line["config"] = {k: c[k] for k in ("workload", "global_batch", "batch_per_gpu", "parallelism", "hipgraph",
                                         "fused_upflow") if k in c}
@@ -653,10 +663,14 @@ def compact_line(full):
         line["cpu_baseline"] = None
     if "per_level_epe_vs_oracle" in full:
         line["per_level_epe_vs_oracle"] = _r(full["per_level_epe_vs_oracle"], 3)
+    if "parity_gate" in full:
+        line["parity_gate"] = {"tol": full["parity_gate"]["tolerance_px"], "pass": full["parity_gate"]["pass"]}
     if "serving_throughput" in full:
         st = full["serving_throughput"]
         line["serving_throughput"] = {"value": _r(st["value"]), "batches_in_flight": st["batches_in_flight"]}
-    if "matmul_bf16x3" in full:
+    if "matmul_bf16x3" in full and "error" in full["matmul_bf16x3"]:
+        line["matmul_bf16x3"] = {"error": full["matmul_bf16x3"]["error"]}
+    elif "matmul_bf16x3" in full:
         mx = full["matmul_bf16x3"]
         line["matmul_bf16x3"] = {"value": _r(mx["value"]), "ms_per_step": _r(mx["ms_per_step"]),
                                  "max_abs_flow_diff_vs_headline_px": _r(mx["max_abs_flow_diff_vs_headline_px"], 3),
@@ -704,7 +718,11 @@ def rehearse_stub(args):
     """--stub-forward: the launcher path and THE timed step loop (dist.timed_steps) with a stub forward on CPU
     tensors under gloo -- what tests/test_dist_cpu.py runs where there is no GPU.  Not a measurement."""
     world, rank, _ = qdist.init("gloo")
-    gather = qdist.EpeGather(6, "cpu", n_local=args.batch)
+    batch = args.batch
+    if args.global_batch:
+        lo, hi = qdist.shard_range(args.global_batch, rank, world)
+        batch = hi - lo
+    gather = qdist.EpeGather(6, "cpu", n_local=batch)
     base = torch.arange(6, dtype=torch.float32)
 
     def run_step(k):
@@ -718,6 +736,10 @@ def rehearse_stub(args):
         print(json.dumps({"metric": "REHEARSAL (stub forward, no kernels): launcher + step loop only",
                           "value": None, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "rehearsal": True,
+                          "scaling": "strong" if args.global_batch else "weak",
+                          "global_batch": args.global_batch or world * args.batch, "batch_rank0": batch,
+                          "allgather": {"ranks_in_allgather": int(per_rank.shape[0]),
+                                        "levels_per_rank": int(per_rank.shape[1]), "backend": "gloo"},
                           "last_step_per_rank": per_rank.tolist(), "last_step_mean": mean.tolist()}))
     if world > 1:
         qdist.barrier()
@@ -745,10 +767,17 @@ def main():
     info = _hip.build_info()
     copy_gbs = device_copy_ceiling(dev)
     hw = (args.height, args.width)
-    result, (weights, pairs_np, flows) = measure(args, args.batch, hw, args.dtype, args.steps, args.warmup,
-                                                 world, rank, dev, True, copy_gbs)
+    batch = args.batch
+    if args.global_batch:
+        if args.global_batch < world:
+            raise SystemExit("--global-batch {} < {} ranks: every rank needs at least one pair".format(
+                args.global_batch, world))
+        lo, hi = qdist.shard_range(args.global_batch, rank, world)
+        batch = hi - lo
+    result, (weights, pairs_np, flows) = measure(args, batch, hw, args.dtype, args.steps, args.warmup,
+                                                 world, rank, dev, True, copy_gbs, args.global_batch)
     result["library"] = info
-    default_run = (world == 1 and args.batch == 8 and hw == (256, 512) and args.dtype == "f32" and
+    default_run = (world == 1 and batch == 8 and not args.global_batch and hw == (256, 512) and args.dtype == "f32" and
                    args.data_format == "channels_last" and not args.no_graph and args.matmul == "f32")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -772,6 +801,17 @@ def main():
                 extra.append({"metric": metric_name((h, w), dt), "error": str(e).splitlines()[0],
                               "config": {"workload": baseline_config_name(b, (h, w), dt, world)}})
         result["extra_configs"] = extra
+    rc = 0
+    if rank == 0 and "per_level_epe_vs_oracle" in result and args.dtype == "f32" and args.matmul == "f32":
+        # the number is gated where it is produced: the flows compared are the ones the TIMED hipGraph wrote
+        # (B-pair batch, two-stream forward), against the CPU oracle on the first --cpu-pairs pairs
+        worst = max(result["per_level_epe_vs_oracle"])
+        result["parity_gate"] = {"tolerance_px": PARITY_TOL_PX, "worst_level_epe_px": worst,
+                                 "pass": bool(worst < PARITY_TOL_PX)}
+        if not worst < PARITY_TOL_PX:   # also catches NaN
+            print("bench.py: PARITY FAILURE: per-level EPE vs the oracle {} >= {} px".format(
+                result["per_level_epe_vs_oracle"], PARITY_TOL_PX), file=sys.stderr)
+            rc = 3
     if rank == 0:
         result["detail_file"] = None
         if args.detail:
@@ -785,7 +825,7 @@ def main():
     if world > 1:
         qdist.barrier()
         torch.distributed.destroy_process_group()
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

@@ -127,12 +127,29 @@ int qpwc_warp_fwd(const void* img, const void* flo, void* out,
  *   nxt_w = WarpV2(nxt, flo); cost = CostVolumeV2(prv, nxt_w)
  * without materialising nxt_w.  NHWC, mode CLAMP, flo dense (B,H,W,2) fp32,
  * search_range 4, C % 4 == 0.  Output addressing as in
- * qpwc_cost_volume_fwd_strided (pass stride d*d, offset 0 for a dense result). */
+ * qpwc_cost_volume_fwd_strided (pass stride d*d, offset 0 for a dense result).
+ * PERFORMANCE NOTE: this entry point always computes what it is asked.  Where the matrix-core
+ * kernels do not apply (qpwc_warp_cost_volume_kernel() names the choice: anything but
+ * "cost_volume_mfma_lds*" means fewer than 256 regions of 8x8 pixels, C % 32 != 0, or a generic
+ * shape) it runs the LDS-tiled vector kernel, which is SLOWER than calling qpwc_warp_fwd +
+ * qpwc_cost_volume_fwd (B=8, 16x32x256: 94 us against 5.6 + 7.8 us).  A caller that wants the
+ * faster of the two asks qpwc_warp_cost_volume_kernel() first, as qpwcnet_amd/non_layers.py does. */
 int qpwc_warp_cost_volume_fwd(const void* prv, const void* nxt, const void* flo, void* out,
                               int B, int H, int W, int C, int search_range,
                               int dtype, float lrelu_slope,
                               int64_t out_pixel_stride, int64_t out_channel_offset,
                               void* stream);
+
+/* Which kernel qpwc_cost_volume_fwd[_strided] (fused == 0) or qpwc_warp_cost_volume_fwd (fused != 0) launches for
+ * this shape with 16-byte aligned operands: the launchers' own selection rules run without enqueuing anything
+ * (host only, no GPU call).  out_pixel_stride <= 0 means dense.  Returns a static string -- one of
+ * "cost_volume_mfma_kernel", "cost_volume_mfma_lds_kernel", "cost_volume_mfma_lds_kernel<true>",
+ * "cost_volume_mfma_lds8x16_warp_kernel", "cost_volume_mfma_lds16_kernel<true>",
+ * "cost_volume_mfma_lds_f16_kernel", "cost_volume_mfma_lds_f16_kernel<true>", "cost_volume_tiled_kernel",
+ * "cost_volume_tiled_kernel<fused>", "cost_volume_generic_kernel" -- or "" for arguments the entry point refuses.
+ * No reference counterpart: a caller's aid for the fused-or-pair decision (see the note above) and for profiles. */
+const char* qpwc_cost_volume_kernel(int B, int H, int W, int C, int search_range, int layout, int dtype,
+                                    int64_t out_pixel_stride, int fused);
 
 /* End-point error (qpwcnet/app/optical_flow/train.py:247-253):
  *   *out_mean = mean over (b,y,x) of || y_true - y_pred ||_2 over the 2 flow channels.
@@ -202,8 +219,8 @@ int qpwc_sepconv3x3_x3_fwd(const void* const* src, const int* src_channels, cons
                            int n_src, int mish_flags, const void* dw, const void* pw3, const void* bias, void* out,
                            int B, int H, int W, int F, void* stream);
 
-/* The same SeparableConv2D for fp16 storage (BASELINE configs[4], mixed_float16 in the reference's
- * train.py; non_layers.py:223-231): sources and `out` fp16, dw (C,3,3) and bias (F) fp32, pw (F, Cpad)
+/* The same SeparableConv2D for fp16 storage (BASELINE configs[4]; the reference itself has no
+ * fp16 path; layer: non_layers.py:223-231): sources and `out` fp16, dw (C,3,3) and bias (F) fp32, pw (F, Cpad)
  * fp16 with Cpad = ceil(C/32)*32, zero padded.  Depthwise in fp32 on the fp16 input, rounded to fp16
  * once, pointwise on the f16 matrix cores with fp32 accumulation; mish_flags as above.  Sources as in
  * qpwc_sepconv3x3_fwd, each a multiple of 4 channels in 8-byte aligned pixels (a last source of fewer
@@ -296,10 +313,12 @@ int qpwc_conv3x3_mish_x3_fwd(const void* x, const void* weight3, const void* bia
 /* src (n) fp32 -> out (3, n) bf16: out[0] = bf16(src), out[1] = bf16(src - out[0]), out[2] = bf16(src - out[0] -
  * out[1]), round to nearest even; src[i] == out[0][i] + out[1][i] + out[2][i] exactly (parts below the smallest normal
  * fp32 flush to zero).
+ * Operands must be finite and below ~3.39e38 in magnitude: bf16(a) overflows to Inf above that and the residual
+ * a - bf16(a) becomes NaN (the fp32-instruction entry points have no such restriction).
  * The weight operands of the *_x3_fwd entry points. */
 int qpwc_split_bf16x3_fwd(const void* src, void* out, long long n, void* stream);
 
-/* The same layer for fp16 storage (BASELINE configs[4]; mixed_float16 in the reference's train.py): x, weight
+/* The same layer for fp16 storage (BASELINE configs[4]; the reference itself has no fp16 path): x, weight
  * ((9, C, C) = [ky*3+kx][out][in]) and out fp16, bias fp32; fp32 accumulation on the fp16 matrix instructions,
  * bias + Mish in fp32, one rounding to fp16 at the store.  Same shapes, padding and alignment rules. */
 int qpwc_conv3x3_mish_f16_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H,

@@ -24,7 +24,7 @@ _ARGUMENT_ERRORS = {E_NULL, E_LAYOUT, E_DTYPE, E_SHAPE, E_RANGE, E_MODE, E_ALIAS
 SYMBOLS = (
     "qpwc_version", "qpwc_last_error", "qpwc_strerror", "qpwc_build_info", "qpwc_device_copy", "qpwc_layout_transpose_fwd", "qpwc_copy_pixels_fwd",
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
-    "qpwc_warp_cost_volume_fwd", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
+    "qpwc_warp_cost_volume_fwd", "qpwc_cost_volume_kernel", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_optflow_tail_fwd", "qpwc_bias_mish_fwd",
     "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd", "qpwc_epe_multi_mixed_fwd",
     "qpwc_cost_volume_to_flow_fwd", "qpwc_sepconv3x3_fwd", "qpwc_sepconv3x3_f16_fwd", "qpwc_bias_mish_pad_fwd", "qpwc_split_frames_pad_fwd",
@@ -80,6 +80,8 @@ def lib():
     L.qpwc_device_copy.restype = ci
     L.qpwc_cost_volume_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp]
     L.qpwc_cost_volume_fwd.restype = ci
+    L.qpwc_cost_volume_kernel.argtypes = [ci, ci, ci, ci, ci, ci, ci, i64, ci]
+    L.qpwc_cost_volume_kernel.restype = ctypes.c_char_p
     L.qpwc_cost_volume_fwd_strided.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, i64, i64, vp]
     L.qpwc_cost_volume_fwd_strided.restype = ci
     L.qpwc_warp_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]

@@ -10,6 +10,15 @@ namespace qpwc {
 
 constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, each with a private L2
 
+// qpwc_cost_volume_kernel(): the launchers of the cost-volume family run their selection rules with this
+// set and report the kernel they WOULD launch instead of launching it (one rule, never a mirrored copy).
+extern thread_local const char* g_dry_kernel;
+extern thread_local bool g_dry_run;
+inline bool dry_run(const char* name) {
+    if (g_dry_run) g_dry_kernel = name;
+    return g_dry_run;
+}
+
 // The flow chain (cost volume, warp, OptFlow, upsample: the critical path of a forward) shares the chip with
 // the decoder's chip-filling launches on a second hardware queue; its waves ask for issue priority over
 // co-resident decoder waves.  (Stream priorities do not survive hipGraph capture on this ROCm.)

@@ -233,6 +233,7 @@ static int launch_tiled(const T* prv, const T* nxt, const float* flo, T* out, in
         set_error("grid too large");
         return QPWC_E_SHAPE;
     }
+    if (dry_run(FUSE ? "cost_volume_tiled_kernel<fused>" : "cost_volume_tiled_kernel")) return QPWC_OK;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NT), 0, s, prv, nxt, flo,
                        out, H, W, C, tiles_x, tiles_y, ops, slope);
     return check_launch("cost_volume_tiled_kernel");
@@ -263,6 +264,7 @@ static int cost_volume_impl(const T* prv, const T* nxt, const float* flo, T* out
         return dispatch_tiled<T, true>(prv, nxt, flo, out, B, H, W, C, ops, slope, s);
     }
     if (fast) return dispatch_tiled<T, false>(prv, nxt, nullptr, out, B, H, W, C, ops, slope, s);
+    if (dry_run("cost_volume_generic_kernel")) return QPWC_OK;
     const int DD = (2 * r + 1) * (2 * r + 1);
     const int64_t total = (int64_t)B * H * W * DD;
     const int64_t want = (total + 255) / 256;
@@ -294,6 +296,7 @@ int cost_volume_launch(const void* prv, const void* nxt, const void* flo, void* 
                        int W, int C, int r, int layout, int dtype, int64_t ops, float slope,
                        bool fuse, bool pad84, hipStream_t s) {
     auto zero_pads = [&]() {
+        if (g_dry_run) return;
         const int64_t npx = (int64_t)B * H * W;
         const unsigned grid = (unsigned)((npx * 3 + 255) / 256 < 4096 ? (npx * 3 + 255) / 256 : 4096);
         if (dtype == QPWC_F32)

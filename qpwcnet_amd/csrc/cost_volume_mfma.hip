@@ -1312,10 +1312,12 @@ static int launch_lds_f16(const __half* prv, const __half* nxt, const float* flo
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
     if (flo) {
+        if (dry_run("cost_volume_mfma_lds_f16_kernel<true>")) return QPWC_OK;
         hipLaunchKernelGGL(cost_volume_mfma_lds_f16_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt, flo,
                            out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
         return check_launch("cost_volume_mfma_lds_f16_kernel<warp>");
     }
+    if (dry_run("cost_volume_mfma_lds_f16_kernel")) return QPWC_OK;
     hipLaunchKernelGGL(cost_volume_mfma_lds_f16_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
                        (const float*)nullptr, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_lds_f16_kernel");
@@ -1379,6 +1381,7 @@ static int launch_lds16(const float* prv, const float* nxt, const float* flo, fl
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
     if (flo) {
+        if (dry_run("cost_volume_mfma_lds16_kernel<true>")) return QPWC_OK;
         hipLaunchKernelGGL(cost_volume_mfma_lds16_kernel<true>, dim3((unsigned)nblk), dim3(1024), 0, s, prv, nxt,
                            flo, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
         return check_launch("cost_volume_mfma_lds16_kernel<warp>");
@@ -1404,6 +1407,7 @@ static int launch_lds8x16_warp(const float* prv, const float* nxt, const float* 
     const int regs_x = (W + 15) / 16, regs_y = (H + 7) / 8;
     const int64_t nblk = (int64_t)regs_x * regs_y * B;
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
+    if (dry_run("cost_volume_mfma_lds8x16_warp_kernel")) return QPWC_OK;
     hipLaunchKernelGGL(cost_volume_mfma_lds8x16_warp_kernel, dim3((unsigned)nblk), dim3(512), 0, s, prv, nxt, flo, out,
                        H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_lds8x16_warp_kernel");
@@ -1425,6 +1429,7 @@ static int launch_lds(const float* prv, const float* nxt, const float* flo, floa
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;
     if (flo) {
+        if (dry_run("cost_volume_mfma_lds_kernel<true>")) return QPWC_OK;
         hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
                            flo, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
         return check_launch("cost_volume_mfma_lds_kernel<warp>");
@@ -1435,6 +1440,7 @@ static int launch_lds(const float* prv, const float* nxt, const float* flo, floa
         if (rc <= 0) return rc;
     }
 #endif
+    if (dry_run("cost_volume_mfma_lds_kernel")) return QPWC_OK;
     hipLaunchKernelGGL(cost_volume_mfma_lds_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, prv, nxt,
                        (const float*)nullptr, out, H, W, C, regs_x, regs_y, (int)ops, slope, inv_c, pad84);
     return check_launch("cost_volume_mfma_lds_kernel");
@@ -1454,6 +1460,7 @@ static int launch_mfma(const T* prv, const T* nxt, T* out, int B, int H, int W, 
         return QPWC_E_SHAPE;
     }
     const float inv_c = (C & (C - 1)) == 0 ? 1.0f / (float)C : 0.0f;  // exact for powers of two
+    if (dry_run("cost_volume_mfma_kernel")) return QPWC_OK;
     hipLaunchKernelGGL((cost_volume_mfma_kernel<T, CPL, KS, WPB>), dim3((unsigned)nblk),
                        dim3(64 * WPB), 0, s, prv, nxt, out, H, W, C, tiles_x, tiles_y, (int)n_tiles,
                        (int)ops, slope, inv_c, pad84);

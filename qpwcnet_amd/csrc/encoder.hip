@@ -424,7 +424,7 @@ static int conv3x3_mish_wide_launch(const void* x, const void* weight, const voi
 }
 
 // ---------------------------------------------------------------------------
-// fp16-storage twin of the two kernels above (BASELINE configs[4]; the reference's mixed_float16 policy, train.py):
+// fp16-storage twin of the two kernels above (BASELINE configs[4]; the reference itself has no fp16 path):
 // x, weight ([9 taps][C out][C in]) and out fp16, bias fp32; products on v_mfma_f32_16x16x32_f16 with fp32
 // accumulation, bias + Mish in fp32, ONE rounding to fp16 at the store (the library path it replaces rounds the
 // convolution output and the activation).  One matrix instruction per tap and 32-channel block where fp32 needs

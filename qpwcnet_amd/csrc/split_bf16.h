@@ -14,6 +14,10 @@
 // such a rounding of the running sum.  Six bf16 instructions of 16 cycles replace eight fp32 instructions of 32 cycles for
 // the same 32-deep slice of the reduction (96 vs 256 cycles).  bf16 has fp32's exponent range, so the split needs no
 // scaling; parts below the smallest normal fp32 flush to zero (absolute error < 2^-126 there).
+// RESTRICTION (finite operands below the bf16 overflow threshold): for |a| >= ~3.39e38 (and +-Inf) bf16(a) rounds to
+// Inf, a - a1 is Inf - Inf = NaN, and the split kernels emit NaN where the fp32 matrix instructions propagate Inf or a
+// finite product.  The opt-in arithmetic is for finite activations / weights (qpwc.h says so by the *_x3_fwd
+// prototypes); the default fp32 path has no such restriction.
 // tests/test_gpu_x3.py compares both arithmetic forms with float64 on the same inputs.
 #pragma once
 #include <hip/hip_runtime.h>

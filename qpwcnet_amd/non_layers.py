@@ -611,11 +611,12 @@ FUSED_FRONT_END_MAX_BYTES = 192 << 20
 
 
 def fused_kernel_applies(prv, search_range=4):
-    """The C side's eligibility rule of the matrix-core fused kernel (cost_volume_mfma_launch), without the size cut."""
+    """True where qpwc_warp_cost_volume_fwd runs one of the matrix-core kernels for this shape -- asked of the C side
+    itself (qpwc_cost_volume_kernel: the launchers' selection rules without a launch), without the size cut."""
     if not (prv.is_cuda and prv.dtype in (torch.float32, torch.float16) and prv.dim() == 4 and search_range == 4):
         return False
     B, H, W, C = prv.shape
-    return C % 32 == 0 and H >= 2 and W >= 2 and B * ((H + 7) // 8) * ((W + 7) // 8) >= 256
+    return ops.cost_volume_kernel(B, H, W, C, prv.dtype, fused=True).startswith("cost_volume_mfma_lds")
 
 
 def fused_front_end_applies(prv, flo=None, search_range=4):

@@ -76,6 +76,20 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def cost_volume_kernel(B, H, W, C, dtype=torch.float32, fused=False, search_range=4, layout=None,
+                       out_pixel_stride=0):
+    """Name of the kernel ``qpwc_cost_volume_fwd`` (``fused=False``) / ``qpwc_warp_cost_volume_fwd`` (``fused=True``)
+    launches for this shape: the C side's own selection rules, run without launching (``qpwc_cost_volume_kernel``;
+    host only).  '' for arguments the entry point refuses."""
+    dt = {"f32": _hip.F32, "f16": _hip.F16}.get(dtype) if isinstance(dtype, str) else _DTYPES.get(dtype)
+    if dt is None:
+        return ""
+    name = _hip.lib().qpwc_cost_volume_kernel(int(B), int(H), int(W), int(C), int(search_range),
+                                              _hip.NHWC if layout is None else layout, dt, int(out_pixel_stride),
+                                              1 if fused else 0)
+    return name.decode() if name else ""
+
+
 def _check_tensor(name, t):
     if not isinstance(t, torch.Tensor):
         raise TypeError("{} must be a torch.Tensor".format(name))

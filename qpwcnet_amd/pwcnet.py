@@ -1,8 +1,12 @@
 """Model assembly mirroring qpwcnet/core/pwcnet.py: ``encoder`` (134-168),
 ``decoder`` (171-207), ``flower`` (28-67), ``build_flower`` (210-244).
 
-The hot path (cost volume + warp, 5 + 4 launches per pair) runs in the HIP
-kernels; everything else is PyTorch-ROCm (MIOpen / hipBLASLt).  Inference only.
+Every layer of the forward runs on the hand-written gfx950 kernels of
+``csrc/`` (cost volume, warps, SeparableConv2D, encoder / decoder convolutions,
+flow heads, EPE) through the C ABI; PyTorch supplies device memory, streams and
+hipGraph capture.  The only library launches left are the two wide pointwise
+GEMMs (``torch.addmm`` -> hipBLASLt) of the first OptFlow layer at the two
+coarsest levels.  Inference only.
 """
 import numpy as np
 import torch

@@ -224,6 +224,20 @@ def test_bench_launches_itself_for_more_than_one_gpu():
     assert d["rehearsal"] is True and d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] is None
     k = 2 + 5 - 1                                         # the drained last result is the last step's
     assert d["last_step_per_rank"] == [[10.0 * k + i for i in range(6)], [10.0 * k + 1000.0 + i for i in range(6)]]
+    assert d["allgather"] == {"ranks_in_allgather": 2, "levels_per_rank": 6, "backend": "gloo"}
+    assert d["scaling"] == "weak" and d["global_batch"] == 16
+    # strong scaling (BASELINE configs[2] is `--gpus 8 --global-batch 64`): 5 pairs over 2 ranks = shards of 3 and 2
+    # (dist.shard_range), the mean weighted by the shard sizes, the line says how many ranks the all-gather saw
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-forward",
+                        "--global-batch", "5", "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["global_batch"] == 5 and d["batch_rank0"] == 3
+    assert d["allgather"]["ranks_in_allgather"] == 2 and d["allgather"]["levels_per_rank"] == 6
+    k = 1 + 3 - 1
+    want = [(3 * (10.0 * k + i) + 2 * (10.0 * k + 1000.0 + i)) / 5 for i in range(6)]
+    assert all(abs(a - b) < 1e-3 for a, b in zip(d["last_step_mean"], want)), (d["last_step_mean"], want)
     # a failing rank makes the launcher fail: --gpus 2 inside a WORLD_SIZE=3 environment is refused by every rank
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-forward"],
                          env=dict(env, WORLD_SIZE="3", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),

@@ -259,7 +259,19 @@ def test_bench_labels_follow_the_arguments():
     assert bench.cost_volume_symbol(8, 128, 256, 32, "f32") == "cost_volume_mfma_lds_kernel"
     assert bench.cost_volume_symbol(32, 128, 256, 32, "f16") == "cost_volume_mfma_lds_f16_kernel"
     assert bench.cost_volume_symbol(8, 16, 32, 256, "f32") == "cost_volume_mfma_kernel"
-    assert bench.cost_volume_symbol(1, 128, 256, 3, "f32") == "cost_volume_tiled_kernel"
+    assert bench.cost_volume_symbol(1, 128, 256, 3, "f32") == "cost_volume_generic_kernel"   # C % 4 != 0
+    assert bench.cost_volume_symbol(1, 128, 256, 12, "f32") == "cost_volume_tiled_kernel"
+    # ... and the fused front end's: the library's OWN rules (qpwc_cost_volume_kernel = a dry run of the launchers),
+    # e.g. config 2's L3 (C = 64, 256 regions of 16 x 16) runs on 8 x 16 regions, config 4's L1-L3 on 16 x 16
+    assert bench.fused_front_symbol(8, 128, 256, 32, "f32", 84) == "cost_volume_mfma_lds8x16_warp_kernel"
+    assert bench.fused_front_symbol(8, 64, 128, 64, "f32") == "cost_volume_mfma_lds8x16_warp_kernel"
+    assert bench.fused_front_symbol(8, 32, 64, 128, "f32") == "cost_volume_mfma_lds_kernel<true>"
+    assert bench.fused_front_symbol(16, 256, 512, 64, "f32") == "cost_volume_mfma_lds16_kernel<true>"
+    assert bench.fused_front_symbol(32, 64, 128, 64, "f16") == "cost_volume_mfma_lds_f16_kernel<true>"
+    assert bench.fused_front_symbol(8, 16, 32, 256, "f32") == "cost_volume_tiled_kernel<fused>"   # 7 x slower than the pair
+    assert bench.fused_front_symbol(8, 1, 32, 256, "f32") == ""                                    # refused: H < 2
+    assert bench.baseline_config_name(8, (256, 512), "f32", 8, 64).startswith("BASELINE configs[2]")
+    assert bench.parse_args(["--global-batch", "64"]).global_batch == 64
     a = bench.parse_args([])
     assert (a.gpus, a.batch, a.height, a.width, a.dtype, a.data_format, a.fused) == (1, 8, 256, 512, "f32", "channels_last", None)
     assert bench.parse_args(["--no-fused"]).fused is False and bench.parse_args(["--fused"]).fused is True
