@@ -107,6 +107,9 @@ class QpwcNet:
         self._sides = []
         # side stream of each decoder level in the two-stream forward (see _forward_two_streams)
         self.dec_stream_of = (0, 0, 0, 0)
+        # round 4 (tools/capture_crosswait.py): the two suspects of the capture SIGSEGV as switches
+        self.allow_returning_dec_streams = False    # a mapping like (0,1,0,1): two side streams waiting on each other
+        self.record_stream_under_capture = True     # Tensor.record_stream on private-pool tensors while capturing
         # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
         # round 3 (tools/step_time.py "dec_chunks=...", three interleaved runs each in one call, ms/step): (2,4,4,4)
         # 1.2147, (2,4,4,2) 1.1996, (2,4,4,1) 1.1991, (2,4,2,2) 1.2005, (2,2,4,1) 1.2031, (2,4,8,8) 1.296: the finest
@@ -253,8 +256,12 @@ class QpwcNet:
         # 0 on ITS stream; a mapping that RETURNS to an earlier stream, e.g. (0,1,0,1), makes two side streams wait on
         # each other alternately and the runtime dies with SIGSEGV while capturing / instantiating the graph -- the
         # round-1 "four staggered streams" crash.  Unsupported by this build: refused here.
-        if any(b < a for a, b in zip(self.dec_stream_of, self.dec_stream_of[1:])) or min(self.dec_stream_of) < 0:
+        if (any(b < a for a, b in zip(self.dec_stream_of, self.dec_stream_of[1:])) and
+                not self.allow_returning_dec_streams) or min(self.dec_stream_of) < 0:
             raise ValueError("dec_stream_of must be non-decreasing side-stream indices, got {}".format(self.dec_stream_of))
+        # tensors allocated under capture come from the graph's private pool and stay referenced (decs) until every
+        # stream has been joined: the graph's own edges order their reuse, the allocator needs no cross-stream note
+        note_streams = self.record_stream_under_capture or not torch.cuda.is_current_stream_capturing()
         n_side = max(self.dec_stream_of) + 1
         while len(self._sides) < n_side:
             self._sides.append(self._side if not self._sides else torch.cuda.Stream(device=encs[-1].device))
@@ -308,7 +315,7 @@ class QpwcNet:
                     # allocated on `side`, read by UpFlow on `main`: tell the caching allocator, so that the block
                     # is not handed to a later side-stream allocation while main may still be reading it (the
                     # join at the end orders main after side, not side's NEXT use after main's reads)
-                    for sd in [main] + sides:
+                    for sd in ([main] + sides) if note_streams else ():
                         if sd is not side:
                             f.record_stream(sd)
                     decs[i] = f

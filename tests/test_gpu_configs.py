@@ -221,3 +221,32 @@ def test_config4_full_network_batch16_graph_first_and_last_pair():
         assert a.shape[0] == B
         e = float(torch_ref.epe_error(a[sub].cpu(), b))
         assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
+
+
+def test_config2_full_network_batch8_graph():
+    """BASELINE configs[1] exactly as bench.py times it -- batch 8, 256x512 fp32, the default two-stream forward
+    (decoder on the side stream, dec_chunks (2,4,4,1)) captured and REPLAYED as a hipGraph, the bench's own synthetic
+    frames (seed 1234) -- per-level EPE of the first and the last pair of the batch against the CPU restatement of
+    build_flower at 1e-4, the bound bench.py now enforces on its own line (parity_gate).  The reference runs its
+    inference the same way: one compiled forward over a batch (app/optical_flow/test_infer.py:62-67,104-105)."""
+    hw, B = (256, 512), 8
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(B, hw[0], hw[1], seed=1234)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV)
+    assert model.overlap_streams and model.matmul == "f32"
+    x = torch.from_numpy(pairs).to(DEV)
+    graph = GraphedForward(model, x)
+    flows, _ = graph.replay(x)
+    flows = [f.clone() for f in flows]
+    flows2, _ = graph.replay(x)                    # a second replay of the same graph writes the same bits
+    assert all(torch.equal(a, b) for a, b in zip(flows, flows2))
+    sub = [0, B - 1]
+    ref = net_ref.RefNet(weights)(pairs[sub])
+    for lvl, (a, b) in enumerate(zip(flows, ref)):
+        assert a.shape[0] == B
+        e = float(torch_ref.epe_error(a[sub].cpu(), b))
+        assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
+    # the eager forward (no capture) of the same model gives the graph's flows bit for bit
+    with torch.no_grad():
+        eager = model(x)
+    assert all(torch.equal(a, b) for a, b in zip(flows, eager))

@@ -381,6 +381,7 @@ def test_decoder_side_stream_mapping_must_not_return_to_an_earlier_stream():
         device = torch.device("cpu")
     m = QpwcNet.__new__(QpwcNet)
     m._side, m._sides, m.dec_stream_of = object(), [], (0, 1, 0, 1)
+    m.allow_returning_dec_streams = False
     import unittest.mock as mock
     with mock.patch("torch.cuda.current_stream", return_value=None):
         with pytest.raises(ValueError, match="non-decreasing"):
