@@ -765,6 +765,10 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 #include "experimental/sepconv_role_split.inc"
 #endif
 
+#ifdef QPWC_SC_FLAT   // lab note (round 4): parity-correct only by luck of the register allocation, slower -- never in the product build
+#include "experimental/sepconv_flat.inc"
+#endif
+
 // ---------------------------------------------------------------------------
 // fp16-storage form of the fused SeparableConv2D (BASELINE configs[4]): either one dense source whose
 // pixels are 16-byte aligned runs of a multiple of 8 channels (OptFlow's layers 2..4, WIDE) or the
@@ -1261,6 +1265,15 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
 #undef QPWC_WS_LAUNCH
             return check_launch("sepconv3x3_ws_kernel");
         }
+    }
+#endif
+#ifdef QPWC_SC_FLAT
+    // round 4: the wide layers of the big levels as ONE flat software pipeline per resident workgroup (sepconv_flat.inc)
+    if (vec && slices == 1 && (F == 64 || F == 128) && nblk >= QPWC_SC_FLAT_MIN_TILES &&
+        (int64_t)H * W * F * 4 < 0x7fffffff) {
+        if (dry_run(F == 128 ? "sepconv3x3_flat_kernel<64> x 2 slices" : "sepconv3x3_flat_kernel<64>")) return QPWC_OK;
+        sepconv_flat_dispatch<64>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, (int)nblk, F / 64, s);
+        return check_launch("sepconv3x3_flat_kernel");
     }
 #endif
     switch (F / slices) {   // outputs per workgroup

@@ -220,6 +220,34 @@ def test_sepconv3x3_fused_resident_workgroups(C, F, act):
     torch.testing.assert_close(out, torch_ref.mish(ref), rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("chans,F", [((84, 32, 2), 128), ((128,), 64), ((40,), 128), ((32,), 64), ((160,), 64)])
+@pytest.mark.parametrize("act", [False, True])
+def test_sepconv3x3_wide_layers_many_tiles(chans, F, act):
+    """The wide layers (F = 64 / 128) on a launch of 1183 ragged tiles (7 images of 100 x 200 pixels = 12.5 x 12.5 tiles:
+    several rounds of workgroups per CU, partial tiles at the right / bottom edges), 1 / 2 / 4 / 5 steps per tile, a
+    three-source first layer with the 2-channel flow tail: against the oracle, and BIT-IDENTICAL to the same images
+    launched one at a time (169 tiles).  Written for round 4's flat-pipeline kernel (csrc/experimental/sepconv_flat.inc,
+    not in the product build: it failed the bit-identity half of this test through a hardware hazard)."""
+    rng = np.random.default_rng(sum(chans) + F)
+    B, H, W = 7, 100, 200
+    assert B * ((H + 7) // 8) * ((W + 15) // 16) >= 1024 > ((H + 7) // 8) * ((W + 15) // 16)
+    C = sum(chans)
+    srcs = [_rand(rng, B, H, W, c) for c in chans]
+    dw = _rand(rng, C, 1, 3, 3)
+    pw = _rand(rng, F, C, 1, 1) / np.sqrt(C)
+    bias = _rand(rng, F)
+    y = torch_ref.depthwise3x3(srcs, dw, act)
+    ref = torch.nn.functional.conv2d(y.permute(0, 3, 1, 2), pw, bias).permute(0, 2, 3, 1)
+    d_srcs, d_dw, d_pw, d_b = [s.to(DEV) for s in srcs], dw.to(DEV), ops.pad_pointwise(pw.to(DEV)), bias.to(DEV)
+    for store_act in (False, True):
+        out = ops.sepconv3x3(d_srcs, d_dw, d_pw, d_b, mish_on_load=act, mish_on_store=store_act)
+        torch.testing.assert_close(out.cpu(), torch_ref.mish(ref) if store_act else ref, rtol=0, atol=5e-5)
+        for b in (0, B - 1):
+            one = ops.sepconv3x3([s[b:b + 1].contiguous() for s in d_srcs], d_dw, d_pw, d_b, mish_on_load=act,
+                                 mish_on_store=store_act)
+            assert torch.equal(out[b:b + 1], one), "image %d differs between the batched and the single-image launch" % b
+
+
 @pytest.mark.parametrize("tail,stride", [(1, 1), (1, 2), (2, 2), (3, 3), (3, 4), (1, 5)])
 def test_sepconv3x3_fused_short_tail_source(tail, stride):
     """The 16-byte path reads a short last source (1..3 channels) with a load that ENDS at its last channel;
