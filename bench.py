@@ -226,6 +226,64 @@ def load_traffic(key):
 
 
 # ---------------------------------------------------------------------------------------------
+def sustained_clock(replay, dev, step_ms):
+    """Shader clock the chip holds UNDER THE STEP: one probe wave (qpwc_clock_probe) stamps (s_memtime, s_memrealtime)
+    pairs every ~15 us on a stream of its own while the step replays back to back; clock = delta(shader ticks) /
+    delta(100 MHz ticks) x 100 MHz per interval.  A pass of its own AFTER the timed region (the probe adds a queue)."""
+    n, sleeps = 3000, 4
+    buf = torch.zeros(2 * n, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream()
+    warm = max(50, int(60.0 / step_ms))           # >= 60 ms of back-to-back steps before the first stamp
+    for _ in range(warm):
+        replay()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _hip.check(_hip.lib().qpwc_clock_probe(buf.data_ptr(), n, sleeps, side.cuda_stream))
+    for _ in range(max(100, int(150.0 / step_ms))):   # the replays outlast the probe (~3000 x 15 us)
+        replay()
+    torch.cuda.synchronize()
+    v = buf.cpu().view(n, 2).double()
+    dt, dr = v[1:, 0] - v[:-1, 0], v[1:, 1] - v[:-1, 1]
+    ok = dr > 0
+    mhz = (dt[ok] / dr[ok] * 100.0).sort().values
+    if mhz.numel() < 10:
+        return None
+    q = lambda f: float(mhz[min(mhz.numel() - 1, int(f * mhz.numel()))])   # noqa: E731
+    span_ms = float((v[-1, 1] - v[0, 1]) / 1e5)
+    return {"median_mhz": q(0.5), "p10_mhz": q(0.1), "p90_mhz": q(0.9), "samples": int(mhz.numel()),
+            "probe_span_ms": span_ms,
+            "f32_matrix_peak_at_median_clock_TFs": 256 * 4 * 64 * q(0.5) * 1e6 / 1e12,
+            "method": "one probe wave stamping s_memtime / s_memrealtime (100 MHz) every ~15 us on its own stream "
+                      "while the step's hipGraph replays back to back; a pass of its own after the timed region"}
+
+
+def config1_kernels(dev, hw, tdtype):
+    """BASELINE configs[0]: ONE 256x512 pair, d = 4 cost volume + WarpV2 (+ the fused front end where its kernel
+    applies) at the five level shapes, B = 1: average launch time (hipGraph of 50 launches, median of 5 rounds)."""
+    out = {}
+    chans = synth.level_channels()
+    g = torch.Generator(device=dev).manual_seed(11)
+    for lv in range(5):
+        shp = (1, hw[0] >> (5 - lv), hw[1] >> (5 - lv), chans[lv])
+        prv = torch.randn(shp, device=dev, generator=g).to(tdtype)
+        nxt = torch.randn(shp, device=dev, generator=g).to(tdtype)
+        flo = torch.randn(shp[:3] + (2,), device=dev, generator=g) * 2
+        e = 4 if tdtype == torch.float32 else 2
+        cv_ms = replay_launches(lambda: ops.cost_volume(prv, nxt))
+        w_ms = replay_launches(lambda: ops.warp(nxt, flo, "clamp"))
+        d = {"shape": "x".join(map(str, shp)),
+             "cost_volume_us": 1e3 * cv_ms, "cost_volume_kernel": ops.cost_volume_kernel(*shp, tdtype),
+             "cost_volume_GBs": cost_volume_bytes(*shp, e) / (cv_ms * 1e-3) / 1e9,
+             "warp_v2_us": 1e3 * w_ms, "warp_v2_GBs": warp_bytes(*shp, e) / (w_ms * 1e-3) / 1e9}
+        fk = ops.cost_volume_kernel(*shp, tdtype, fused=True)
+        if fk.startswith("cost_volume_mfma_lds"):
+            f_ms = replay_launches(lambda: ops.warp_cost_volume(prv, nxt, flo))
+            d.update({"fused_us": 1e3 * f_ms, "fused_kernel": fk})
+        out["L%d" % lv] = d
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(weights, pairs_np, n_pairs, reps, gpu_flows, hw):
     """The reference-algorithm CPU restatement (TF2 itself cannot run offline) on the host cores:
     the two hot-path ops op for op (oracle/torch_ref.py: 81 x slice*mul*mean + concat + lrelu; gather
@@ -596,6 +654,17 @@ def measure(args, B, hw, dtype, steps, warmup, world, rank, dev, headline, copy_
             model.matmul = "f32"
         del ref_flows
 
+    # ---- the shader clock the chip sustains under this step (reported, never used to scale anything)
+    if headline and graphs is not None and world == 1 and not args.no_inflight:
+        try:
+            res["sustained_clock"] = sustained_clock(graphs[0].replay, dev, res["ms_per_step"])
+        except (RuntimeError, ValueError, AttributeError) as e:
+            res["sustained_clock"] = {"error": str(e).splitlines()[0][:160]}
+        try:
+            res["config1_kernels_B1"] = config1_kernels(dev, hw, tdtype)
+        except (RuntimeError, ValueError) as e:
+            res["config1_kernels_B1"] = {"error": str(e).splitlines()[0][:160]}
+
     # ---- live rooflines (single stream, HIP events)
     blocks, hot = rooflines(model, pairs, B, hw, dtype, tdtype, dev, args, copy_gbs)
     # the dominant hot-path launch of THIS step: the fused WarpV2 + cost volume where UpFlow uses it at L4, the
@@ -679,6 +748,12 @@ def compact_line(full):
     line["library"] = "{} v{}{}".format(lib.get("build"), lib.get("version"), "" if lib.get("product") else " NOT-PRODUCT")
     line["detail"] = full.get("detail_file")
     line["whole_step"] = {k: _r(v) for k, v in full["whole_step"].items()}
+    sc = full.get("sustained_clock")
+    if sc and "median_mhz" in sc:
+        line["whole_step"]["clock_mhz"] = _r(sc["median_mhz"], 4)
+        line["whole_step"]["frac_of_peak_at_that_clock"] = _r(
+            full["whole_step"]["achieved"] / sc["f32_matrix_peak_at_median_clock_TFs"], 3) \
+            if full.get("dtype") == "f32" else None
     if "extra_configs" in full:
         ex = []
         for r in full["extra_configs"]:

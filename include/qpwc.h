@@ -83,6 +83,12 @@ int qpwc_copy_pixels_fwd(const void* src, void* dst, int B, int H, int W, int C,
  * Not part of the reference's surface. */
 int qpwc_device_copy(const void* src, void* dst, int64_t bytes, void* stream);
 
+/* Measurement aid: ONE wave writes n_samples pairs (s_memtime = shader-clock ticks, s_memrealtime = 100 MHz ticks) into
+ * out_pairs (2 * n_samples uint64), sleeping sleeps_per_sample x s_sleep 127 between stamps, then ends.  Launched on a
+ * stream of its own beside the work under test, delta(s_memtime) / delta(s_memrealtime) x 100 MHz is the shader clock
+ * the chip sustains under that work (bench.py: `sustained_clock_mhz`).  Not part of the reference's surface. */
+int qpwc_clock_probe(void* out_pairs, int n_samples, int sleeps_per_sample, void* stream);
+
 /* CostVolume / CostVolumeV2 forward.
  * Replaces: CostVolume.call           qpwcnet/core/layers.py:72-100
  *           CostVolumeV2.call         qpwcnet/core/layers.py:128-132, i.e. the op

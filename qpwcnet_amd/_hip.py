@@ -22,7 +22,7 @@ _ARGUMENT_ERRORS = {E_NULL, E_LAYOUT, E_DTYPE, E_SHAPE, E_RANGE, E_MODE, E_ALIAS
 
 # every symbol include/qpwc.h declares
 SYMBOLS = (
-    "qpwc_version", "qpwc_last_error", "qpwc_strerror", "qpwc_build_info", "qpwc_device_copy", "qpwc_layout_transpose_fwd", "qpwc_copy_pixels_fwd",
+    "qpwc_version", "qpwc_last_error", "qpwc_strerror", "qpwc_build_info", "qpwc_device_copy", "qpwc_clock_probe", "qpwc_layout_transpose_fwd", "qpwc_copy_pixels_fwd",
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_cost_volume_kernel", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
     "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_optflow_tail_fwd", "qpwc_bias_mish_fwd",
@@ -76,6 +76,8 @@ def lib():
     L.qpwc_layout_transpose_fwd.restype = ci
     L.qpwc_copy_pixels_fwd.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(i64), ctypes.POINTER(i64), ci, vp]
     L.qpwc_copy_pixels_fwd.restype = ci
+    L.qpwc_clock_probe.argtypes = [vp, ci, ci, vp]
+    L.qpwc_clock_probe.restype = ci
     L.qpwc_device_copy.argtypes = [vp, vp, i64, vp]
     L.qpwc_device_copy.restype = ci
     L.qpwc_cost_volume_fwd.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp]

@@ -206,6 +206,31 @@ int qpwc_copy_pixels_fwd(const void* src, void* dst, int B, int H, int W, int C,
                               dst_strides[0] * es, dst_strides[1] * es, dst_strides[2] * es, (hipStream_t)stream);
 }
 
+// One wave that stamps (shader-clock counter, 100 MHz real-time counter) pairs while it sleeps: the sustained clock of
+// the chip under whatever runs beside it is delta(s_memtime) / delta(s_memrealtime) x 100 MHz
+// (MI355X_MICROARCH.md, constants table).  Bounded: n_samples stamps, then the wave ends.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, int n_samples,
+                                                         int sleeps_per_sample) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n_samples; ++i) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+        out[2 * i] = t;
+        out[2 * i + 1] = r;
+        for (int k = 0; k < sleeps_per_sample; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
+int qpwc_clock_probe(void* out_pairs, int n_samples, int sleeps_per_sample, void* stream) {
+    if (!out_pairs) return fail(QPWC_E_NULL, "null pointer argument");
+    if (n_samples <= 0 || n_samples > (1 << 20) || sleeps_per_sample < 0 || sleeps_per_sample > 4096)
+        return fail(QPWC_E_SHAPE, "clock probe: 1..2^20 samples of 0..4096 sleeps");
+    if ((uintptr_t)out_pairs % 8) return fail(QPWC_E_ALIGN, "clock probe buffer must be 8-byte aligned");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out_pairs,
+                       n_samples, sleeps_per_sample);
+    return check_launch("clock_probe_kernel");
+}
+
 int qpwc_device_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     if (!src || !dst) return fail(QPWC_E_NULL, "null pointer argument");
     if (bytes <= 0 || bytes % 16) return fail(QPWC_E_SHAPE, "bytes must be a positive multiple of 16");

@@ -79,7 +79,14 @@ __device__ __forceinline__ void warp_nhwc_body(const T* __restrict__ img, const 
     const int64_t total = (int64_t)B * H * W * nch;
     // two independent items per thread and trip: 2 flow reads, then 8 corner gathers in flight
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx0 < total; idx0 += 2 * stride) {
+    // Round 4: workgroups are dealt round-robin over the 8 XCDs; in plain grid order eight neighbouring 32- / 64-pixel
+    // runs land on eight different L2s and every XCD gathers from everywhere in the image -- the request-size
+    // counters (TCC_EA0_RDREQ_128B: all of a launch's fabric reads are 128-byte lines) showed 1.92 x the compulsory
+    // read bytes for the fp16 kernel at config 5's L4 (64-byte pixels: each line fetch brings a neighbour pixel that
+    // another XCD then fetches again) and 1.18 x for fp32.  An XCD now takes a CONTIGUOUS run of the launch's items
+    // (xcd_swizzle: bijective, same items, same arithmetic), so neighbouring rows meet in one L2.
+    const int64_t bid = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    for (int64_t idx0 = bid * blockDim.x + threadIdx.x; idx0 < total; idx0 += 2 * stride) {
         const int64_t idx1 = idx0 + stride;
         const bool two = idx1 < total;
         int ch[2], x[2], y[2], b[2];

@@ -9,7 +9,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$root"
 rm -f profiles/traffic.json
 for cfg in 2 4 5; do
-  if [ "$cfg" = 2 ]; then passes=""; pre=""; else passes="C D E F"; pre="c${cfg}_"; fi
+  if [ "$cfg" = 2 ]; then passes=""; pre=""; else passes="C D E F H I"; pre="c${cfg}_"; fi
   PMC_PASSES="$passes" tools/pmc.sh cv84_c$cfg -- python3 tools/cv84_launch.py --config $cfg
   if [ "$cfg" = 5 ]; then cv=cost_volume_mfma_lds_f16_kernel; else cv=cost_volume_mfma_lds_kernel; fi
   python3 tools/traffic_from_pmc.py gpurun_out/pmc_cv84_c$cfg profiles/traffic.json "$tag" \

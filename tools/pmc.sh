@@ -25,6 +25,8 @@ passes=(
  "E:FETCH_SIZE"
  "F:WRITE_SIZE"
  "G:GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"
+ "H:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
+ "I:TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"
 )
 # PMC_PASSES="E F": only those passes (e.g. the two HBM-traffic counters)
 for p in "${passes[@]}"; do
