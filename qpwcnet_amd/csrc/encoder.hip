@@ -266,26 +266,33 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
 // ds_read_b128 from the halo tile and feeds 4 matrix instructions; LDS pixels are C floats with the
 // 16-byte chunk q of halo pixel p at q ^ (p & 15) (16 consecutive pixels of one chunk cover all banks).
 // Replaces library convolution (73 TF) + bias/Mish pass (+ a zeroing launch for its split-K variants).
-template <int C, int TH>
-__global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* __restrict__ x,
-                                                                   const float* __restrict__ weight,
-                                                                   const float* __restrict__ bias,
-                                                                   float* __restrict__ out, int H, int W,
-                                                                   int pad_h, int pad_w, int tiles_x,
-                                                                   int tiles_y, int n_tiles) {
+// Round 4, KS = 2 -- measured +-0, not launched by the product build (QPWC_ENC_KSPLIT_MINC) -- for the 128- / 256-channel
+// levels, whose 256 workgroups are ONE wave per SIMD (every LDS or weight wait of that wave idles the SIMD's matrix
+// pipe, 0.55 busy at the 2.4 GHz the chip holds under this kernel, tools/clock_under.py): the workgroup has EIGHT waves -- waves 4-7 take the second half of
+// the input-channel blocks for the same four output blocks, each wave loads only its half's weights (the weight
+// traffic of the launch does not change), and the two halves meet in LDS before bias + Mish: two waves per SIMD with
+// half the matrix instructions each, one hiding the other's waits.  The sum is (first half) + (second half) instead
+// of one chain: another fp32 rounding order of the same products.
+template <int C, int TH, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_mish_wide_kernel(
+    const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int pad_h, int pad_w, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int NT = 256 * KS;                   // threads
     constexpr int NQ = C / 4;                      // 16-byte chunks per pixel
     constexpr int HH = TH + 2, NH = HH * kEcHW;    // halo rows / pixels
     constexpr int NKB = C / 32;                    // 32-channel blocks of the reduction
-    constexpr int NST = (NH * NQ + 255) / 256;     // staging loads per thread
+    constexpr int NST = (NH * NQ + NT - 1) / NT;   // staging loads per thread
+    static_assert(NKB % KS == 0, "the K halves are whole 32-channel blocks");
     __shared__ __attribute__((aligned(16))) float in_s[NH * C];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ow = wave & 3, kh = wave >> 2;       // output block of the slice, half of the reduction
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int slice = blockIdx.x / n_tiles;                       // 64 outputs
     const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int X0 = tx * kEcTW, Y0 = ty * TH;
-    const int fo = 64 * slice + 16 * wave;                        // this wave's output block
+    const int fo = 64 * slice + 16 * ow;                          // this wave's output block
     const float* xb = x + (int64_t)b * H * W * C;
 
     // ---- stage the halo tile (zero outside the image): all loads first, then the LDS writes ----
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
         float4 st[NST];
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
-            const int idx = tid + 256 * it;
+            const int idx = tid + NT * it;
             const int hp = idx / NQ, q = idx - hp * NQ;
             const int hy = hp / kEcHW, hx = hp - hy * kEcHW;
             const int gy = Y0 - 1 + hy, gx = X0 - 1 + hx;
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
         }
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
-            const int idx = tid + 256 * it;
+            const int idx = tid + NT * it;
             const int hp = idx / NQ, q = idx - hp * NQ;
             if (idx < NH * NQ) *reinterpret_cast<float4*>(in_s + hp * C + 4 * (q ^ (hp & 15))) = st[it];
         }
@@ -321,11 +328,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
             for (int kc = 0; kc < 2; ++kc)
                 w[k][kc] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)k * C + fo + n) * C + 32 * kb + 16 * kc + 4 * g);
     };
-    load_w(wv, 0);
+    const int kb0 = kh * (NKB / KS), kb1 = kb0 + NKB / KS;
+    load_w(wv, kb0);
     __syncthreads();   // the halo tile is complete (the first weight loads are in flight behind it)
 #pragma unroll 1
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + 1 < NKB) load_w(wn, kb + 1);
+    for (int kb = kb0; kb < kb1; ++kb) {
+        if (kb + 1 < kb1) load_w(wn, kb + 1);
 #if QPWC_ENC_PIPE
         // one step = (tap, 16-channel chunk): TH ds_read_b128 feed 4 TH matrix instructions; the reads of step i + 1
         // are issued before the matrix instructions of step i (the wide levels run one wave per SIMD: nothing else
@@ -379,6 +387,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) wv[k][kc] = wn[k][kc];
     }
+    if (KS > 1) {
+        // the second half's sums travel through LDS (the halo tile is dead once every wave has left the loop)
+        __syncthreads();
+        f32x4e* red = reinterpret_cast<f32x4e*>(in_s) + (ow * TH) * 64 + lane;
+        if (kh == 1) {
+#pragma unroll
+            for (int m = 0; m < TH; ++m) red[m * 64] = acc[m];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int m = 0; m < TH; ++m) acc[m] += red[m * 64];
+        }
+    }
     // ---- bias + Mish: lane = pixel n of tile row m, outputs fo + 4g .. + 3 ----
     const int Ho = H + pad_h, Wo = W + pad_w;
     float* ob = out + (int64_t)b * Ho * Wo * C;
@@ -386,14 +408,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
 #pragma unroll
     for (int m = 0; m < TH; ++m) {
         const int gy = Y0 + m, gx = X0 + n;
-        if (gy < H && gx < W)
+        if (kh == 0 && gy < H && gx < W)
             *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + gx) * C + fo + 4 * g) =
                 make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
                             enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
     }
     // ---- zero border of the padded output, this slice's 64 channels, written by the edge tiles ----
     if (pad_w > 0 && X0 + kEcTW >= W) {
-        for (int i = tid; i < TH * pad_w * 16; i += 256) {
+        for (int i = tid; i < TH * pad_w * 16; i += NT) {
             const int q = i & 15, r = i >> 4, col = r % pad_w, row = r / pad_w;
             const int gy = Y0 + row;
             if (gy < H) *reinterpret_cast<float4*>(ob + ((int64_t)gy * Wo + W + col) * C + 64 * slice + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -401,13 +423,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mish_wide_kernel(const float* 
     }
     if (pad_h > 0 && Y0 + TH >= H) {
         const int x_end = (X0 + kEcTW >= W) ? Wo : X0 + kEcTW;   // the corner belongs to the last tile
-        for (int i = tid; i < pad_h * (x_end - X0) * 16; i += 256) {
+        for (int i = tid; i < pad_h * (x_end - X0) * 16; i += NT) {
             const int q = i & 15, r = i >> 4, col = r % (x_end - X0), row = r / (x_end - X0);
             *reinterpret_cast<float4*>(ob + ((int64_t)(H + row) * Wo + X0 + col) * C + 64 * slice + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
 
+#ifndef QPWC_ENC_KSPLIT_MINC
+#define QPWC_ENC_KSPLIT_MINC (1 << 30)   // channel count from which the wide stride-1 kernel splits its reduction over 8 waves.
+                                         // Round 4, one call (tools/encbench.py, us): never / from 128 / from 64 channels: C = 64 28.9 / 28.7 /
+                                         // 31.4, C = 128 28.1 / 28.5 / 27.6, C = 256 29.2 / 31.3 / 30.7; step 1.1773 / 1.1778 / 1.1790 ms --
+                                         // a second wave per SIMD does not fill the matrix pipe either: never (the form stays, tested)
+#endif
 template <int C, int TH>
 static int conv3x3_mish_wide_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H,
                                     int W, int pad_h, int pad_w, hipStream_t s) {
@@ -417,9 +445,14 @@ static int conv3x3_mish_wide_launch(const void* x, const void* weight, const voi
         set_error("conv3x3_mish: too many tiles");
         return QPWC_E_SHAPE;
     }
-    hipLaunchKernelGGL((conv3x3_mish_wide_kernel<C, TH>), dim3((unsigned)(n_tiles * (C / 64))), dim3(256), 0, s,
-                       (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, pad_h, pad_w,
-                       tiles_x, tiles_y, (int)n_tiles);
+    if (C >= QPWC_ENC_KSPLIT_MINC)
+        hipLaunchKernelGGL((conv3x3_mish_wide_kernel<C, TH, 2>), dim3((unsigned)(n_tiles * (C / 64))), dim3(512), 0, s,
+                           (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, pad_h, pad_w,
+                           tiles_x, tiles_y, (int)n_tiles);
+    else
+        hipLaunchKernelGGL((conv3x3_mish_wide_kernel<C, TH, 1>), dim3((unsigned)(n_tiles * (C / 64))), dim3(256), 0, s,
+                           (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, pad_h, pad_w,
+                           tiles_x, tiles_y, (int)n_tiles);
     return check_launch("conv3x3_mish_wide_kernel");
 }
 
