@@ -990,6 +990,9 @@ __global__ __launch_bounds__(1024) void cost_volume_mfma_lds16_kernel(
 // each) and still stages every nxt pixel 3 x instead of 4 x (24 + 8 = 32 block loads per 8 tiles = 4 per tile).
 //   pieces : block B = it*4 + (wave >> 1), it = 0..7: blocks 0..23 = nxt (bi, bj) = (B / 6, B % 6) of the 16-row x
 //            24-column neighbourhood, 24..31 = prv tile B - 24; every lane stages 6 nxt + 2 prv pieces per step.
+#ifndef QPWC_R8_PRV_FIRST
+#define QPWC_R8_PRV_FIRST 0   // A/B (round 4): the two prv pieces requested before the first round of gathers -- 50.5-51.4 vs 49.1-49.5 us in one call: off
+#endif
 #ifndef QPWC_R8_PR
 #define QPWC_R8_PR 3   // A/B: 6 = every gather of the first step in one round: 48.0-48.8 vs 47.3-47.8 us, not better
 #endif
@@ -1076,9 +1079,22 @@ __global__ __launch_bounds__(512, 2) void cost_volume_mfma_lds8x16_warp_kernel(
         auto mix = [&](int q) __attribute__((always_inline)) {
             return blend_clamp_chunk(ax[q], ay[q], c[q][0], c[q][1], c[q][2], c[q][3]);
         };
+        // Round 4 (QPWC_R8_PRV_FIRST): in the first step -- no accumulator is live -- the two prv pieces, which depend on
+        // nothing, are requested BEFORE the first round of gathers instead of after the last one, where their round trip
+        // stood between the last blend and the barrier in front of the matrix phase.
+        constexpr bool PRV_FIRST = FIRST && QPWC_R8_PRV_FIRST;
+        u32x4 pp0, pp1;
+        if (PRV_FIRST) {
+            pp0 = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[0], soff, 0);
+            pp1 = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[1], soff, 0);
+        }
 #pragma unroll
         for (int q = 0; q < PR; ++q) issue(q, q);
         if (!FIRST) __syncthreads();  // previous step's operand reads are done
+        if (PRV_FIRST) {
+            *reinterpret_cast<u32x4*>(smem + lds_w + 6 * 8192) = pp0;
+            *reinterpret_cast<u32x4*>(smem + lds_w + 7 * 8192) = pp1;
+        }
 #pragma unroll
         for (int it = 0; it < 6; it += PR) {
             u32x4 v[PR];
@@ -1087,15 +1103,17 @@ __global__ __launch_bounds__(512, 2) void cost_volume_mfma_lds8x16_warp_kernel(
             if (it + PR < 6) {
 #pragma unroll
                 for (int q = 0; q < PR; ++q) issue(it + PR + q, q);
-            } else {   // last round: the two prv pieces ride in the freed registers
+            } else if (!PRV_FIRST) {   // last round: the two prv pieces ride in the freed registers
                 c[0][0] = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[0], soff, 0);
                 c[0][1] = __builtin_amdgcn_raw_buffer_load_b128(rp, goffp[1], soff, 0);
             }
 #pragma unroll
             for (int q = 0; q < PR; ++q) *reinterpret_cast<u32x4*>(smem + lds_w + (it + q) * 8192) = v[q];
         }
-        *reinterpret_cast<u32x4*>(smem + lds_w + 6 * 8192) = c[0][0];
-        *reinterpret_cast<u32x4*>(smem + lds_w + 7 * 8192) = c[0][1];
+        if (!PRV_FIRST) {
+            *reinterpret_cast<u32x4*>(smem + lds_w + 6 * 8192) = c[0][0];
+            *reinterpret_cast<u32x4*>(smem + lds_w + 7 * 8192) = c[0][1];
+        }
         if (FIRST) asm volatile("" : "+v"(tab.x), "+v"(tab.y), "+v"(tab.z), "+v"(tab.w));
         __syncthreads();
 #pragma unroll
