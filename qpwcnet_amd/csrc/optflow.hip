@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                     // 1 and 2 of a 1-channel source with stride 1 or 2) would start in front of it: they read forward
                     const bool fwd = b == 0 && off < (unsigned)back;
                     if (ok && tail && !fwd) off -= (unsigned)back;
-                    st4[it] = *reinterpret_cast<const float4*>(q + (int)off);   // |off| < 2^31 (launcher); negative for pixel 0 of image b > 0
+                    st4[it] = ldg_f4(q + (int)off);   // global_load, not flat (optflow_common.h); |off| < 2^31 (launcher); negative for pixel 0 of image b > 0
                 }
             }
         }
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
             }
             float st[NST];
 #pragma unroll
-            for (int it = 0; it < NST; ++it) st[it] = (p && goff[it] >= 0) ? p[(int64_t)goff[it] * ps] : 0.0f;
+            for (int it = 0; it < NST; ++it) st[it] = (p && goff[it] >= 0) ? ldg_f1(p + (int64_t)goff[it] * ps) : 0.0f;
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
                 const int hp = sps + SPT * it;
@@ -741,6 +741,10 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 #include "experimental/sepconv_role_split.inc"
 #endif
 
+#ifdef QPWC_SC_PP     // lab note (round 4): eight-wave ping-pong, make ab ABSRC=optflow ABFLAGS=-DQPWC_SC_PP=1
+#include <type_traits>
+#include "experimental/sepconv_pp.inc"
+#endif
 #ifdef QPWC_SC_FLAT   // lab note (round 4): parity-correct only by luck of the register allocation, slower -- never in the product build
 #include "experimental/sepconv_flat.inc"
 #endif
@@ -847,6 +851,17 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
 #undef QPWC_WS_LAUNCH
             return check_launch("sepconv3x3_ws_kernel");
         }
+    }
+#endif
+#ifdef QPWC_SC_PP
+    if (QPWC_SC_PP && vec && slices == 1 && (F == 64 || F == 128) && nblk >= QPWC_SC_PP_MIN_TILES &&
+        (int64_t)H * W * F * 4 < 0x7fffffff) {
+        if (dry_run(F == 128 ? "sepconv3x3_pp_kernel<128>" : "sepconv3x3_pp_kernel<64>")) return QPWC_OK;
+        if (F == 128)
+            sepconv_pp_dispatch<128>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, (int)nblk, s);
+        else
+            sepconv_pp_dispatch<64>(d, act, fdw, fpw, fb, (float*)out, H, W, C, cpad, tiles_x, tiles_y, (int)nblk, s);
+        return check_launch("sepconv3x3_pp_kernel");
     }
 #endif
 #ifdef QPWC_SC_FLAT

@@ -23,6 +23,42 @@ struct DwSrc {
     int64_t stride[3];  // floats per pixel of each source
 };
 
+// ---- loads that are GLOBAL, said so (round 4) ----
+// A pointer that comes out of a by-value struct (DwSrc) or out of a select against a __device__ constant is a GENERIC
+// pointer to the compiler: it emits flat_load_*, and a flat load counts on lgkmcnt as well as on vmcnt -- so every
+// `s_waitcnt lgkmcnt(0)` in front of an LDS operand (the first ds_read of a matrix or depthwise phase) also waits for
+// the whole prefetch that was issued a moment earlier.  The fused SeparableConv2D kernels requested a step's inputs
+// "one step ahead" since round 1 and paid their full memory latency at the top of every step: the SUM of memory time
+// and matrix time that every profile of these kernels showed (found in round 4 with s_memtime stamps around the
+// request: 4.3-5.4 k cycles for nine load instructions).  These helpers cast to address space 1: global_load_*, vmcnt
+// only.
+#ifndef QPWC_LDG_GLOBAL
+#define QPWC_LDG_GLOBAL 1   // 0 = generic pointers again (A/B builds: what rounds 1-3 ran)
+#endif
+#if QPWC_LDG_GLOBAL
+#define QPWC_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define QPWC_GLOBAL_AS
+#endif
+typedef float qpwc_f32x4g __attribute__((ext_vector_type(4)));
+typedef unsigned qpwc_u32x4g __attribute__((ext_vector_type(4)));
+typedef unsigned qpwc_u32x2g __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldg_f4(const float* p) {
+    const qpwc_f32x4g v = *(const QPWC_GLOBAL_AS qpwc_f32x4g*)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float ldg_f1(const float* p) { return *(const QPWC_GLOBAL_AS float*)p; }
+__device__ __forceinline__ uint4 ldg_u4(const void* p) {
+    const qpwc_u32x4g v = *(const QPWC_GLOBAL_AS qpwc_u32x4g*)p;
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint2 ldg_u2(const void* p) {
+    const qpwc_u32x2g v = *(const QPWC_GLOBAL_AS qpwc_u32x2g*)p;
+    return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ unsigned ldg_u1(const void* p) { return *(const QPWC_GLOBAL_AS unsigned*)p; }
+__device__ __forceinline__ unsigned short ldg_h1(const void* p) { return *(const QPWC_GLOBAL_AS unsigned short*)p; }
+
 // tile / step geometry of the fused SeparableConv2D kernels (fp32 and fp16 storage)
 constexpr int kScKC = 32;               // channels per step
 constexpr int kScTH = 8, kScTW = 16;    // pixel tile

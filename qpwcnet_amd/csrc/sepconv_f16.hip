@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, (RES && WIDE && F <= 32) ? 3 : 2) void sepconv
 #pragma unroll
             for (int it = 0; it < NST; ++it)
                 st[it] = (goff[it] >= 0 && c < C)
-                             ? *reinterpret_cast<const uint4*>(sb + (int64_t)goff[it] * src.stride[0] + c)
+                             ? ldg_u4(sb + (int64_t)goff[it] * src.stride[0] + c)   // global_load, not flat (optflow_common.h)
                              : make_uint4(0, 0, 0, 0);
         } else {
             const __half* p = nullptr;
@@ -123,14 +123,14 @@ __global__ __launch_bounds__(256, (RES && WIDE && F <= 32) ? 3 : 2) void sepconv
             if (left >= 4) {
 #pragma unroll
                 for (int it = 0; it < NST; ++it)
-                    st2[it] = goff[it] >= 0 ? *reinterpret_cast<const uint2*>(p + (int64_t)goff[it] * ps)
+                    st2[it] = goff[it] >= 0 ? ldg_u2(p + (int64_t)goff[it] * ps)
                                             : make_uint2(0, 0);
             } else if (left == 2 && (ps & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
                 // Flow/UpFlow's 2-channel flow: ONE 4-byte load per pixel
 #pragma unroll
                 for (int it = 0; it < NST; ++it)
                     st2[it] = goff[it] >= 0
-                                  ? make_uint2(*reinterpret_cast<const unsigned*>(p + (int64_t)goff[it] * ps), 0u)
+                                  ? make_uint2(ldg_u1(p + (int64_t)goff[it] * ps), 0u)
                                   : make_uint2(0, 0);
             } else {   // any other short last source: element loads
 #pragma unroll
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(256, (RES && WIDE && F <= 32) ? 3 : 2) void sepconv
                     unsigned short h[4] = {0, 0, 0, 0};
                     if (goff[it] >= 0 && left > 0) {
                         const unsigned short* q = reinterpret_cast<const unsigned short*>(p + (int64_t)goff[it] * ps);
-                        h[0] = q[0];
-                        if (left > 1) h[1] = q[1];
-                        if (left > 2) h[2] = q[2];
+                        h[0] = ldg_h1(q);
+                        if (left > 1) h[1] = ldg_h1(q + 1);
+                        if (left > 2) h[2] = ldg_h1(q + 2);
                     }
                     st2[it] = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
                 }
