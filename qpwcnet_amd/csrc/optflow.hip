@@ -305,6 +305,9 @@ __device__ long long g_sc_census[4096 * 6];   // per workgroup: start, staged0, 
 
 __device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifndef QPWC_SC_BIAS_EARLY
+#define QPWC_SC_BIAS_EARLY 1   // A/B (round 4): the last step's bias values requested before its matrix instructions
+#endif
 #ifndef QPWC_SC_ASYM_PRIO
 #define QPWC_SC_ASYM_PRIO 0   // A/B: asymmetric wave priority inside the fused SeparableConv2D (see the kernel)
 #endif
@@ -690,8 +693,19 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 ook[m] = gy < H && gx < W;
                 orow[m] = out + ((int64_t)(eb * H + gy) * W + gx) * FT + 4 * g;
             }
+            // Round 4: ALL of the lane's bias values are requested here, before the first matrix instruction of the step.
+            // Loaded inside epilogue(ft), each block's load sat right in front of its use behind an `s_waitcnt vmcnt(0)` --
+            // and on gfx950 vmcnt counts STORES too, so every block also waited for the previous block's two output stores
+            // to be acknowledged: the last step of a tile took 11.5-12 k cycles against 5 k for the others (stamps of the
+            // ping-pong lab kernel, which shares this epilogue).
+            float4 bvs[QPWC_SC_BIAS_EARLY ? NFT : 1];
+            if (QPWC_SC_BIAS_EARLY) {
+#pragma unroll
+                for (int ft = 0; ft < NFT; ++ft) bvs[ft] = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+            }
             auto epilogue = [&](int ft) __attribute__((always_inline)) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+                const float4 bv = QPWC_SC_BIAS_EARLY ? bvs[QPWC_SC_BIAS_EARLY ? ft : 0]
+                                                     : *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,

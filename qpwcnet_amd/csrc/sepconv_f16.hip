@@ -22,6 +22,9 @@ constexpr int kDwHoistC = 128;      // widest layer (padded channels) whose taps
 #ifndef QPWC_SC16_DEEP
 #define QPWC_SC16_DEEP 0            // A/B (round 4): two staged steps in flight in the one-shot form -- measured +-0 (L4 B=32: 258.3 vs 261.2, 171.4 vs 172.8 us): the kernel is not bound by its bytes in flight
 #endif
+#ifndef QPWC_SC16_BIAS_EARLY
+#define QPWC_SC16_BIAS_EARLY 1      // A/B (round 4): bias values requested before the last matrix step
+#endif
 #ifndef QPWC_SC16_WIDE_STORES
 #define QPWC_SC16_WIDE_STORES 0     // A/B (round 4): 16-byte output stores through v_permlane16_swap -- parity-green, +-0 (config 5 step 1.679 vs 1.656 ms with both switches on): off
 #endif
@@ -342,6 +345,15 @@ __global__ __launch_bounds__(256, (RES && WIDE && F <= 32) ? 3 : 2) void sepconv
         commit_w();
         __syncthreads();
         if (RES && nsteps == 1) zero_acc();
+        // Round 4: the lane's bias values are requested BEFORE the last matrix step.  Loaded per block inside the store loop
+        // each load sat behind an `s_waitcnt vmcnt(0)` in front of its use, and vmcnt counts stores on gfx950: every block
+        // waited for the previous block's output stores to be acknowledged (the fp32 kernel's last step: 11.5 k cycles
+        // against 5 k for the others, optflow.hip).
+        float4 bvs[QPWC_SC16_BIAS_EARLY ? NFT : 1];
+        if (QPWC_SC16_BIAS_EARLY) {
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) bvs[ft] = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+        }
         pointwise(y_s + ((nsteps - 1) & 1) * kYh);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -350,7 +362,8 @@ __global__ __launch_bounds__(256, (RES && WIDE && F <= 32) ? 3 : 2) void sepconv
             const bool ok = gy < H && gx < W;
             __half* o = out + ((int64_t)(eb * H + gy) * W + gx) * F;
             auto finish = [&](int ft) __attribute__((always_inline)) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+                const float4 bv = QPWC_SC16_BIAS_EARLY ? bvs[QPWC_SC16_BIAS_EARLY ? ft : 0]
+                                                       : *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
                 float4 z = make_float4(acc[m][ft][0] + bv.x, acc[m][ft][1] + bv.y, acc[m][ft][2] + bv.z,
                                        acc[m][ft][3] + bv.w);
                 if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
