@@ -623,9 +623,13 @@ __global__ __launch_bounds__(256) void conv3x3_mish_f16_kernel(const __half* __r
         }
     }
     // ---- bias + Mish, one rounding to fp16: lane = pixel n of tile row RW wave + r, outputs f0 + 16 ft + 4g .. + 3 ----
+    // (all bias values requested before the first store: a load behind stores waits for them too, vmcnt counts both)
+    float4 bqs[NFT];
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) bqs[ft] = *reinterpret_cast<const float4*>(bias + f0 + 16 * ft + 4 * g);
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
-        const float4 bq = *reinterpret_cast<const float4*>(bias + f0 + 16 * ft + 4 * g);
+        const float4 bq = bqs[ft];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int gy = Y0 + RW * wave + r, gx = X0 + n;
@@ -752,9 +756,13 @@ __global__ __launch_bounds__(256, C == 16 ? 4 : 3) void conv3x3_mish_f16_narrow_
         __builtin_amdgcn_sched_barrier(0);
     }
     // ---- bias + Mish, one rounding to fp16: lane = pixel n of tile row RW wave + r, outputs 16 ft + 4g .. + 3 ----
+    // (all bias values requested before the first store: a load behind stores waits for them too, vmcnt counts both)
+    float4 bqs[NFT];
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) bqs[ft] = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft) {
-        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+        const float4 bq = bqs[ft];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int gy = Y0 + RW * wave + r, gx = X0 + n;
@@ -1290,9 +1298,10 @@ __global__ __launch_bounds__(256, 4) void conv3x3s2_mish_kernel(const float* __r
                         acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][ft][t], bv[m][t], acc[m][ft], 0, 0, 0);
         }
     float* ob = out + (int64_t)b * Ho * Wo * CO;
+    const float4 bq2[2] = {*reinterpret_cast<const float4*>(bias + 4 * g), *reinterpret_cast<const float4*>(bias + 16 + 4 * g)};
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
-        const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+        const float4 bq = bq2[ft];     // (both requested before the first store: vmcnt counts stores too)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int gy = Y0 + 2 * wave + m, gx = X0 + n;
