@@ -27,6 +27,7 @@ passes=(
  "G:GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"
  "H:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
  "I:TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"
+ "J:SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_DATA_FIFO_FULL"
 )
 # PMC_PASSES="E F": only those passes (e.g. the two HBM-traffic counters)
 for p in "${passes[@]}"; do

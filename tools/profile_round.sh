@@ -13,6 +13,8 @@ cd "$root"
 out=gpurun_out/profiles_$tag
 mkdir -p "$out"
 bash tools/make_traffic.sh "$tag" > "$out/make_traffic.log" 2>&1 || echo "make_traffic failed"
+PMC_PASSES="A B C G J" tools/pmc.sh sep -- python3 tools/sepbench.py --levels 4 --iters 2 > "$out/pmc_sep.log" 2>&1
+python3 tools/pmc_summary.py gpurun_out/pmc_sep sepconv3x3_fused_kernel > profiles/${tag}_pmc_sepconv_fused_L4.txt 2>> "$out/pmc_sep.log"
 python3 tools/kbench.py --json profiles/${tag}_kbench.json > "$out/kbench_c2.log" 2>&1
 python3 tools/kbench.py --batch 16 --res 1024x2048 --levels 1,2,3,4 --iters 10 --json profiles/${tag}_kbench_config4.json > "$out/kbench_c4.log" 2>&1
 python3 tools/kbench.py --batch 32 --dtype f16 --json profiles/${tag}_kbench_config5.json > "$out/kbench_c5.log" 2>&1
