@@ -10,6 +10,12 @@ namespace qpwc {
 
 constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, each with a private L2
 
+// A/B (round 4): Mish with an explicit `x > 20 ? x : m` per value (1) or without (0: the clamped exponent already gives
+// m = x to 2 ulp there; one compare + one select less per activation, ~160 M activations per step)
+#ifndef QPWC_MISH_SELECT
+#define QPWC_MISH_SELECT 0
+#endif
+
 // qpwc_cost_volume_kernel(): the launchers of the cost-volume family run their selection rules with this
 // set and report the kernel they WOULD launch instead of launching it (one rule, never a mirrored copy).
 extern thread_local const char* g_dry_kernel;

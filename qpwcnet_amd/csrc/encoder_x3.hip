@@ -20,7 +20,11 @@ __device__ __forceinline__ float x3_mishf(float x) {
     const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
     const float t = e * (e + 2.0f);
     const float m = x * (t * __builtin_amdgcn_rcpf(t + 2.0f));
+#if QPWC_MISH_SELECT
     return x > 20.0f ? x : m;
+#else
+    return m;   // x > 20: e is clamped, t / (t + 2) rounds to 1 +- 1 ulp, m = x to 2 ulp -- no compare + select per value
+#endif
 }
 
 constexpr int kX3TW = 16, kX3HW = kX3TW + 2;

@@ -305,6 +305,17 @@ __device__ long long g_sc_census[4096 * 6];   // per workgroup: start, staged0, 
 
 __device__ __attribute__((aligned(16))) const float kScZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifndef QPWC_SC_W_AHEAD
+#define QPWC_SC_W_AHEAD 1   // A/B (round 4): pointwise A operands read one block of eight matrix instructions ahead (F = 128)
+#endif
+#ifndef QPWC_SC_AGPR
+#define QPWC_SC_AGPR 0   // A/B (round 4): accumulators pinned to AGPRs -- every matrix instruction then accumulates in place (no renamed
+                         // result, 0 suspects in tools/mfma_war_lint.py) but the epilogue pays a v_accvgpr_read per value: 129-131 vs 123-126 us
+#endif
+#ifndef QPWC_SC_BUF_STORE
+#define QPWC_SC_BUF_STORE 1   // A/B (round 4): output stores through a buffer descriptor (no per-store address arithmetic / branch)
+#endif
+typedef unsigned u32x4sc __attribute__((ext_vector_type(4)));
 #ifndef QPWC_SC_BIAS_EARLY
 #define QPWC_SC_BIAS_EARLY 1   // A/B (round 4): the last step's bias values requested before its matrix instructions
 #endif
@@ -382,7 +393,12 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int i = 0; i < NFT; ++i) acc[m][i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NFT; ++i) {
+            acc[m][i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#if QPWC_SC_AGPR
+            asm volatile("" : "+a"(acc[m][i]));   // accumulators live in the AGPR half of the register file (see QPWC_SC_AGPR)
+#endif
+        }
 
     // ---- staging map --------------------------------------------------------------
     // generic: lane = channel (32 lanes = 128 contiguous bytes of one pixel), 8 halo pixels per trip
@@ -581,6 +597,37 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
         }
     };
     auto pointwise = [&](const float* ys) {   // D[f][px] += W[f][k] * y[px][k] on the matrix cores
+        if (QPWC_SC_W_AHEAD && F >= 128) {   // (F = 64: 76.3 vs 73.3 us at L4 with it, F = 128: 124 vs 126)
+            // Round 4: a block's A operand is read while the block BEFORE it multiplies (both B operands up front).  As the
+            // compiler placed them, every eight matrix instructions ended in `ds_read_b128; s_waitcnt lgkmcnt(0)` for the
+            // next eight: ~90 cycles of an idle matrix pipe per 256 (ISA of round 3's build).
+            f32x4v yv[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    yv[u][m] = *reinterpret_cast<const f32x4v*>(ys + (32 * wave + 16 * m + n) * kScKC + (((4 * u + g) ^ sw) << 2));
+            auto read_w = [&](int j) __attribute__((always_inline)) {   // j = u * NFT + ft
+                const int u = j / NFT, ft = j - u * NFT;
+                return *reinterpret_cast<const f32x4v*>(w_s + (16 * ft + n) * kScKC + (((4 * u + g) ^ sw) << 2));
+            };
+            f32x4v wv = read_w(0);
+#pragma unroll
+            for (int j = 0; j < 2 * NFT; ++j) {
+                const int u = j / NFT, ft = j - u * NFT;
+                f32x4v wn;
+                if (j + 1 < 2 * NFT) wn = read_w(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], yv[u][m][t], acc[m][ft], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < 2 * NFT) wv = wn;
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int coff = ((4 * u + g) ^ sw) << 2;
@@ -686,13 +733,24 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                     yv[u][m] = *reinterpret_cast<const f32x4v*>(ys + (32 * wave + 16 * m + n) * kScKC + (((4 * u + g) ^ sw) << 2));
             float* orow[2];
             bool ook[2];
+            int ooff[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int pix = 32 * wave + 16 * m + n;
                 const int gy = eY0 + pix / kScTW, gx = eX0 + pix % kScTW;
                 ook[m] = gy < H && gx < W;
                 orow[m] = out + ((int64_t)(eb * H + gy) * W + gx) * FT + 4 * g;
+                // buffer form: offset inside the tile's band of rows; a column past the image is an out-of-range offset
+                // (a row past it is past the descriptor's end): the store is dropped, no branch, no 64-bit address
+                ooff[m] = gx < W ? (((pix / kScTW) * W + gx) * FT + 4 * g) * 4 : (int)0x80000000;
             }
+            // Round 4: outputs through a buffer descriptor over the tile's band of (at most) 8 rows.  With pointers the
+            // compiler re-derived the 64-bit address of every store from (image, row, column) -- v_mad_u64_u32, two
+            // v_mul_lo_u32, v_add3, two v_lshl_add_u64 and an exec-mask branch per store, 16 stores per lane -- to keep
+            // two pointers out of the register budget during the matrix phase.
+            const int band_rows = min(kScTH, H - eY0);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                out + (int64_t)(eb * H + eY0) * W * FT, 0, band_rows * W * FT * 4 - fslice * F * 4, 0x00020000);
             // Round 4: ALL of the lane's bias values are requested here, before the first matrix instruction of the step.
             // Loaded inside epilogue(ft), each block's load sat right in front of its use behind an `s_waitcnt vmcnt(0)` --
             // and on gfx950 vmcnt counts STORES too, so every block also waited for the previous block's two output stores
@@ -712,7 +770,13 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                                            acc[m][ft][3] + bv.w);
                     // the activation applied once per output element instead of once per (halo) load of the next layer
                     if (ACT_OUT) z = make_float4(mishf(z.x), mishf(z.y), mishf(z.z), mishf(z.w));
-                    if (ook[m]) *reinterpret_cast<float4*>(orow[m] + 16 * ft) = z;
+                    if (QPWC_SC_BUF_STORE)
+                        // (the block's 64 * ft bytes go into the instruction's immediate offset, NOT the scalar offset: with a
+                        // REGISTER there hipcc assumes the store has read its data when the next instruction issues and lets
+                        // the Mish of the next values overwrite v[4:7] right behind `buffer_store_dwordx4 v[4:7], .., s4 offen`
+                        // -- on gfx950 it has not: channel 4g+1 of one block came out as garbage, run-to-run different)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4sc, z), ro, ooff[m] + 64 * ft, 0, 0);
+                    else if (ook[m]) *reinterpret_cast<float4*>(orow[m] + 16 * ft) = z;
                 }
             };
 #pragma unroll
@@ -814,6 +878,10 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
     const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
     if (nblk > INT32_MAX) {
         set_error("sepconv3x3: too many tiles");
+        return QPWC_E_SHAPE;
+    }
+    if (QPWC_SC_BUF_STORE && (int64_t)kScTH * W * F * 4 >= 0x7fffffff) {   // the output descriptor spans a tile's band of rows
+        set_error("sepconv3x3: 8 rows of outputs must stay below 2 GiB");
         return QPWC_E_SHAPE;
     }
     // few tiles (coarse pyramid levels): split the outputs over 2 / 4 / 8 workgroups per tile (slices of >= 16
