@@ -47,12 +47,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwSrc src, const float* 
     const T* p;
     int64_t ps;
     int cc;
-    if (c < src.ch[0]) {
-        p = (const T*)src.ptr[0]; ps = src.stride[0]; cc = c;
-    } else if (c < src.ch[0] + src.ch[1]) {
-        p = (const T*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
-    } else {
-        p = (const T*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
+    {
+        const DwPick k = dwsrc_pick(src, c, C);
+        p = (const T*)k.p; ps = k.ps; cc = k.cc;
     }
     p += (int64_t)b * H * W * ps + cc;
 
@@ -431,15 +428,9 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
             int ps = 0;
             int left = 0;   // channels of the source from c on
             if (c < C) {
-                int cc;
-                if (c < src.ch[0]) {
-                    p = (const float*)src.ptr[0]; ps = (int)src.stride[0]; cc = c; left = src.ch[0] - c;
-                } else if (c < src.ch[0] + src.ch[1]) {
-                    p = (const float*)src.ptr[1]; ps = (int)src.stride[1]; cc = c - src.ch[0]; left = src.ch[0] + src.ch[1] - c;
-                } else {
-                    p = (const float*)src.ptr[2]; ps = (int)src.stride[2]; cc = c - src.ch[0] - src.ch[1]; left = C - c;
-                }
-                p += (int64_t)b * H * W * ps + cc;
+                const DwPick k = dwsrc_pick(src, c, C);
+                p = (const float*)k.p; ps = (int)k.ps; left = k.left;
+                p += (int64_t)b * H * W * ps + k.cc;
             }
             {
                 // branch-free: halo pixels outside the image and channels past C read a 16-byte block of zeros;
@@ -494,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
                 left = (c < e0 ? e0 : (c < e1 ? e1 : nfull)) - c;
             }
             const bool tail = left < 4;
-            const unsigned ps_tail = (unsigned)src.stride[src.ch[2] ? 2 : (src.ch[1] ? 1 : 0)];   // a tail is in the last source
+            const unsigned ps_tail = (unsigned)(src.ch[2] ? src.stride[2] : (src.ch[1] ? src.stride[1] : src.stride[0]));   // a tail is in the last source
             if (__builtin_amdgcn_ballot_w64(tail) != 0) {
 #pragma unroll
                 for (int it = 0; it < NST; ++it) {
@@ -522,15 +513,9 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
             const float* p = nullptr;
             int64_t ps = 0;
             if (c < C) {
-                int cc;
-                if (c < src.ch[0]) {
-                    p = (const float*)src.ptr[0]; ps = src.stride[0]; cc = c;
-                } else if (c < src.ch[0] + src.ch[1]) {
-                    p = (const float*)src.ptr[1]; ps = src.stride[1]; cc = c - src.ch[0];
-                } else {
-                    p = (const float*)src.ptr[2]; ps = src.stride[2]; cc = c - src.ch[0] - src.ch[1];
-                }
-                p += (int64_t)b * H * W * ps + cc;
+                const DwPick k = dwsrc_pick(src, c, C);
+                p = (const float*)k.p; ps = k.ps;
+                p += (int64_t)b * H * W * ps + k.cc;
             }
             float st[NST];
 #pragma unroll

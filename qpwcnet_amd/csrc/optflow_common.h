@@ -21,11 +21,56 @@ __device__ __forceinline__ float mishf(float x) {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef QPWC_DWSRC_REGS
+#define QPWC_DWSRC_REGS 1   // A/B (round 4): see dwsrc_in_registers()
+#endif
+
 struct DwSrc {
     const void* ptr[3];
     int ch[3];          // channels taken from each source (0 = unused)
     int64_t stride[3];  // floats per pixel of each source
 };
+
+// Round 4: a DwSrc arrives by value, i.e. in the kernel-argument segment, and `cond ? src.ptr[0] : src.ptr[1]` under a
+// per-lane condition is folded by the optimiser into ONE load through a per-lane selected ADDRESS of the field: a
+// `global_load_dwordx2` from the argument segment, `s_waitcnt vmcnt(0)` (which also drains every load issued before it),
+// 64-bit address arithmetic on the result, and only then the data loads -- two dependent memory round trips in front of
+// every step's request, in every kernel that reads a virtual concat (found in the ISA behind the step's second barrier;
+// it is the "request phase of 2.8-5.9 k cycles" of the phase stamps).  The fields pass through an opaque scalar-register
+// barrier -- no: both a local struct copy and nine scalars behind an asm barrier ended up in SCRATCH memory, indexed the same
+// way (the branches' loads are merged into one load through a selected address before the locals are promoted to
+// registers).  What works is to have no branch at all: dwsrc_pick() below.
+// which source of the virtual concat holds channel c -- BRANCH-FREE: all nine fields are read unconditionally (scalar
+// loads of kernel arguments) and combined with masks; with QPWC_DWSRC_REGS = 0 the old if / else-if chain (A/B)
+struct DwPick {
+    const void* p;   // base pointer of the source
+    int64_t ps;      // its pixel stride (elements)
+    int cc;          // channel inside the source
+    int left;        // channels of the source from c on (C - c in the last one)
+};
+__device__ __forceinline__ DwPick dwsrc_pick(const DwSrc& s, int c, int C) {
+    DwPick r;
+#if QPWC_DWSRC_REGS
+    const uint64_t p0 = (uint64_t)s.ptr[0], p1 = (uint64_t)s.ptr[1], p2 = (uint64_t)s.ptr[2];
+    const int64_t s0 = s.stride[0], s1 = s.stride[1], s2 = s.stride[2];
+    const int e0 = s.ch[0], e1 = e0 + s.ch[1];
+    const bool in0 = c < e0, in1 = !in0 && c < e1;
+    const uint64_t m0 = 0ull - (uint64_t)in0, m1 = 0ull - (uint64_t)in1, m2 = ~(m0 | m1);
+    r.p = (const void*)((p0 & m0) | (p1 & m1) | (p2 & m2));
+    r.ps = (int64_t)(((uint64_t)s0 & m0) | ((uint64_t)s1 & m1) | ((uint64_t)s2 & m2));
+    r.cc = c - ((e0 & (int)m1) | (e1 & (int)m2));
+    r.left = ((e0 & (int)m0) | (e1 & (int)m1) | (C & (int)m2)) - c;
+#else
+    if (c < s.ch[0]) {
+        r.p = s.ptr[0]; r.ps = s.stride[0]; r.cc = c; r.left = s.ch[0] - c;
+    } else if (c < s.ch[0] + s.ch[1]) {
+        r.p = s.ptr[1]; r.ps = s.stride[1]; r.cc = c - s.ch[0]; r.left = s.ch[0] + s.ch[1] - c;
+    } else {
+        r.p = s.ptr[2]; r.ps = s.stride[2]; r.cc = c - s.ch[0] - s.ch[1]; r.left = C - c;
+    }
+#endif
+    return r;
+}
 
 // ---- loads that are GLOBAL, said so (round 4) ----
 // A pointer that comes out of a by-value struct (DwSrc) or out of a select against a __device__ constant is a GENERIC

@@ -113,15 +113,9 @@ __global__ __launch_bounds__(256, (RES && WIDE && F <= 32) ? 3 : 2) void sepconv
             const __half* p = nullptr;
             int ps = 0, left = 0;   // channels of the source from c on
             if (c < C) {
-                int cc;
-                if (c < src.ch[0]) {
-                    p = (const __half*)src.ptr[0]; ps = (int)src.stride[0]; cc = c; left = src.ch[0] - c;
-                } else if (c < src.ch[0] + src.ch[1]) {
-                    p = (const __half*)src.ptr[1]; ps = (int)src.stride[1]; cc = c - src.ch[0]; left = src.ch[0] + src.ch[1] - c;
-                } else {
-                    p = (const __half*)src.ptr[2]; ps = (int)src.stride[2]; cc = c - src.ch[0] - src.ch[1]; left = C - c;
-                }
-                p += (int64_t)b * H * W * ps + cc;
+                const DwPick k = dwsrc_pick(src, c, C);
+                p = (const __half*)k.p; ps = (int)k.ps; left = k.left;
+                p += (int64_t)b * H * W * ps + k.cc;
             }
             if (left >= 4) {
 #pragma unroll
