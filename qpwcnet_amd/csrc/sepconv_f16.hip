@@ -1,5 +1,9 @@
 // fp16-storage SeparableConv2D of OptFlow (BASELINE configs[4]): its own translation unit since round 4 (the fp32
 // kernels of optflow.hip take two minutes to compile; the two now build in parallel).
+#ifndef QPWC_DWSRC_REGS
+#define QPWC_DWSRC_REGS 0   // the branch-free source selection of optflow_common.h measured +-0 .. +2 % here (first layer, L4 B=32:
+                            // 242-248 vs 238-244 us; config 5 step 1.619-1.624 vs 1.609-1.611 ms): this file keeps the if-chain
+#endif
 #include "optflow_common.h"
 
 namespace qpwc {
