@@ -99,6 +99,9 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 #ifndef QPWC_UPCONV_PIPE
 #define QPWC_UPCONV_PIPE 0
 #endif
+#ifndef QPWC_ENC_NARROW_EARLY
+#define QPWC_ENC_NARROW_EARLY 0   // A/B (round 4): narrow fp32 kernel, weights (C = 16) + bias requested with the tile's inputs: 32.4 vs 32.3, 30.2 vs 30.3 us, step +-0 -- off
+#endif
 #ifndef QPWC_ENC_PIPE
 #define QPWC_ENC_PIPE 1   // operand reads of the wide fp32 kernels issued this many steps ahead (0 = as the compiler places them)
 #endif
@@ -166,6 +169,27 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
     ENC_CENSUS(0);
     float4 st[NLD];
     stage_load(tid0, tx0, st);
+    // Round 4 (one tile per workgroup): the first output block's weights and every bias value are requested HERE, with the
+    // tile's inputs, and land under the same wait.  As the compiler placed them, each tap's weights were loaded a few matrix
+    // instructions ahead of their use behind counted vmcnt waits, and the bias right before the epilogue behind
+    // `s_waitcnt vmcnt(0)` -- L2-hit latencies exposed inside a 2.3 k-cycle matrix phase.
+    constexpr bool EARLYB = QPWC_ENC_NARROW_EARLY && NT == 1;   // every bias value
+    constexpr bool EARLY = EARLYB && C == 16;                   // ... and the weights (C = 32: 18 requests with 18 address pairs on top
+                                                                // of the staged tile spill 29-33 registers under the 128 of four waves per SIMD)
+    f32x4e wpre[EARLY ? 9 : 1][EARLY ? NKC : 1];
+    float4 bpre[EARLYB ? NFT : 1];
+    if (EARLYB) {
+        if (EARLY) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc)
+                    wpre[k][kc] = *reinterpret_cast<const f32x4e*>(weight + ((int64_t)k * C + n0) * C + 16 * kc + 4 * g0);
+        }
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) bpre[ft] = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // also a compiler barrier: the loads above stay above
+    }
 #ifdef QPWC_ENC_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -191,12 +215,18 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
             // weights of output block ft for this lane: row f = 16 ft + n, channels 16 kc + 4g .. + 3, 9 taps
-            f32x4e wv[9][NKC];
+            f32x4e wld[EARLY ? 1 : 9][EARLY ? 1 : NKC];
+            if (!EARLY) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
+                for (int k = 0; k < 9; ++k)
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc)
-                    wv[k][kc] = *reinterpret_cast<const f32x4e*>(wt + ((int64_t)k * C + 16 * ft + n) * C + 16 * kc + 4 * g);
+                    for (int kc = 0; kc < NKC; ++kc)
+                        wld[k][kc] = *reinterpret_cast<const f32x4e*>(wt + ((int64_t)k * C + 16 * ft + n) * C + 16 * kc + 4 * g);
+            }
+            auto wv = [&](int k, int kc) __attribute__((always_inline)) -> f32x4e& {
+                if constexpr (EARLY) return wpre[k][kc];
+                else return wld[k][kc];
+            };
             f32x4e acc[2];
             acc[0] = f32x4e{0.f, 0.f, 0.f, 0.f};
             acc[1] = f32x4e{0.f, 0.f, 0.f, 0.f};
@@ -220,11 +250,19 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
                         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                             for (int m = 0; m < 2; ++m)
-                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][tt], bv[m][tt], acc[m], 0, 0, 0);
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv(ky * 3 + kx, kc)[tt], bv[m][tt], acc[m], 0, 0, 0);
+                        // the next output block's weights of this (tap, chunk) are requested as soon as its registers are free:
+                        // a whole block of matrix work lies between the request and the first use
+                        if (EARLY && ft + 1 < NFT) {
+                            __builtin_amdgcn_sched_barrier(0);   // (unfenced, the scheduler hoists these requests: two register sets, 33 spilled)
+                            wpre[ky * 3 + kx][kc] = *reinterpret_cast<const f32x4e*>(
+                                wt + ((int64_t)(ky * 3 + kx) * C + 16 * (ft + 1) + n) * C + 16 * kc + 4 * g);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
             if (ft == NFT - 1) ENC_CENSUS(3);
             // ---- bias + Mish: lane = pixel n of tile row 2 wave + m, outputs 16 ft + 4g .. + 3 ----
-            const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
+            const float4 bq = EARLYB ? bpre[ft] : *reinterpret_cast<const float4*>(bias + 16 * ft + 4 * g);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int gy = Y0 + 2 * wave + m, gx = X0 + n;
