@@ -99,6 +99,22 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 #ifndef QPWC_UPCONV_PIPE
 #define QPWC_UPCONV_PIPE 0
 #endif
+// Round 4: the next block's weights are requested UNCONDITIONALLY (the last trip re-reads its own block, an L1 hit).  With
+// `if (kb + 1 < NKB) load_w(...)` the compiler's s_waitcnt pass must be right for the trip that issued no request as well, so
+// it waited with vmcnt(7), (6), .. (0) through the trip's eight groups of matrix instructions -- i.e. for the requests that
+// were issued a moment ago at the top of THIS trip, one by one, instead of for the ones issued a whole trip earlier
+// (vmcnt is a counter of outstanding requests, in order): an L2 round trip exposed at the top of every 32-channel block.
+#ifndef QPWC_W_NEXT_ALWAYS
+#define QPWC_W_NEXT_ALWAYS 1
+#endif
+#ifndef QPWC_W_NEXT_ALWAYS_F16
+#define QPWC_W_NEXT_ALWAYS_F16 0   // the fp16 kernels (16-cycle matrix instructions, two waves per SIMD) lose with it: config 5 1.627-1.629 vs 1.604-1.611 ms
+#endif
+#if QPWC_W_NEXT_ALWAYS
+#define QPWC_LOAD_W_NEXT(END) load_w(wn, kb + 1 < (END) ? kb + 1 : kb)
+#else
+#define QPWC_LOAD_W_NEXT(END) do { if (kb + 1 < (END)) load_w(wn, kb + 1); } while (0)
+#endif
 #ifndef QPWC_ENC_NARROW_EARLY
 #define QPWC_ENC_NARROW_EARLY 0   // A/B (round 4): narrow fp32 kernel, weights (C = 16) + bias requested with the tile's inputs: 32.4 vs 32.3, 30.2 vs 30.3 us, step +-0 -- off
 #endif
@@ -373,9 +389,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_mish_wide_k
     const int kb0 = kh * (NKB / KS), kb1 = kb0 + NKB / KS;
     load_w(wv, kb0);
     __syncthreads();   // the halo tile is complete (the first weight loads are in flight behind it)
-#pragma unroll 1
-    for (int kb = kb0; kb < kb1; ++kb) {
-        if (kb + 1 < kb1) load_w(wn, kb + 1);
+    // one 32-channel block with the weights in `wv`; the two register sets alternate (QPWC_W_NEXT_ALWAYS)
+    auto block = [&](f32x4e (&wv)[9][2], int kb) __attribute__((always_inline)) {
 #if QPWC_ENC_PIPE
         // one step = (tap, 16-channel chunk): TH ds_read_b128 feed 4 TH matrix instructions; the reads of step i + 1
         // are issued before the matrix instructions of step i (the wide levels run one wave per SIMD: nothing else
@@ -424,11 +439,32 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_mish_wide_k
                             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[m][t], acc[m], 0, 0, 0);
                 }
 #endif
+    };
+#if QPWC_W_NEXT_ALWAYS
+    {
+        int kb = kb0;
+#pragma unroll 1
+        for (; kb + 1 < kb1; kb += 2) {
+            load_w(wn, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);   // (unfenced, the scheduler sinks the requests to just in front of their use)
+            block(wv, kb);
+            load_w(wv, kb + 2 < kb1 ? kb + 2 : kb);   // (last trip: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            block(wn, kb + 1);
+        }
+        if (kb < kb1) block(wv, kb);   // odd number of blocks
+    }
+#else
+#pragma unroll 1
+    for (int kb = kb0; kb < kb1; ++kb) {
+        if (kb + 1 < kb1) load_w(wn, kb + 1);
+        block(wv, kb);
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) wv[k][kc] = wn[k][kc];
     }
+#endif
     if (KS > 1) {
         // the second half's sums travel through LDS (the halo tile is dead once every wave has left the loop)
         __syncthreads();
@@ -578,9 +614,8 @@ __global__ __launch_bounds__(256) void conv3x3_mish_f16_kernel(const __half* __r
         };
         load_w(wv, 0);
         __syncthreads();
-#pragma unroll 1
-        for (int kb = 0; kb < NKB; ++kb) {
-            if (kb + 1 < NKB) load_w(wn, kb + 1);
+        // one 32-channel block with the weights in `wv`; the two register sets alternate (QPWC_W_NEXT_ALWAYS)
+        auto block = [&](f16x8e (&wv)[9], int kb) __attribute__((always_inline)) {
 #if QPWC_ENC16_PIPE
             // one step = one tap: TH ds_read_b128 feed TH matrix instructions of 16 cycles each; the reads of tap
             // t + 1 go out before the matrix instructions of tap t (round 3: as the compiler placed them every matrix
@@ -615,9 +650,30 @@ __global__ __launch_bounds__(256) void conv3x3_mish_f16_kernel(const __half* __r
                 }
             }
 #endif
+        };
+#if QPWC_W_NEXT_ALWAYS_F16
+        {
+            int kb = 0;
+#pragma unroll 1
+            for (; kb + 1 < NKB; kb += 2) {
+                load_w(wn, kb + 1);
+                __builtin_amdgcn_sched_barrier(0);   // (unfenced, the scheduler sinks the requests to just in front of their use)
+                block(wv, kb);
+                load_w(wv, kb + 2 < NKB ? kb + 2 : kb);   // (last trip: a harmless re-read)
+                __builtin_amdgcn_sched_barrier(0);
+                block(wn, kb + 1);
+            }
+            if (kb < NKB) block(wv, kb);   // odd number of blocks
+        }
+#else
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb + 1 < NKB) load_w(wn, kb + 1);
+            block(wv, kb);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) wv[tap] = wn[tap];
         }
+#endif
         const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
 #pragma unroll
         for (int r = 0; r < TH; ++r) {
@@ -953,9 +1009,9 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
     };
     load_w(wv, 0);
     __syncthreads();
-#pragma unroll 1
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + 1 < NKB) load_w(wn, kb + 1);
+    // one 32-channel block of the reduction with the weights in `wv` (the two register sets alternate: no copy, and
+    // every trip issues the same requests, so the compiler's vmcnt counts are exact -- see QPWC_W_NEXT_ALWAYS)
+    auto block = [&](f32x4e (&wv)[4][2], int kb) __attribute__((always_inline)) {
         // QPWC_UPCONV_PIPE: 1 = every level, 2 = the finest decoder level (C = 64) only
         if constexpr (QPWC_UPCONV_PIPE == 1 || (QPWC_UPCONV_PIPE == 2 && C == 64)) {
         // one step = (tap, 16-channel chunk); the operand reads of step i + 1 go out before the matrix instructions of
@@ -998,10 +1054,28 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
                         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][kc][j], bv[m][j], acc[m], 0, 0, 0);
             }
         }
+    };
+    static_assert(NKB % 2 == 0, "two blocks per trip");
+    if constexpr (QPWC_W_NEXT_ALWAYS && NKB > 2) {   // (C = 64, two blocks: +-0, and 5 spilled registers at TH = 8)
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; kb += 2) {
+            load_w(wn, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);        // (unfenced, the scheduler sinks the requests to just in front of their use)
+            block(wv, kb);
+            load_w(wv, kb + 2 < NKB ? kb + 2 : kb);   // (last trip: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            block(wn, kb + 1);
+        }
+    } else {
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb + 1 < NKB) load_w(wn, kb + 1);
+            block(wv, kb);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) wv[t][kc] = wn[t][kc];
+                for (int kc = 0; kc < 2; ++kc) wv[t][kc] = wn[t][kc];
+        }
     }
     const int H2 = 2 * H, W2 = 2 * W;
     float* ob = out + (int64_t)b * H2 * W2 * out_pixel_stride;
@@ -1100,9 +1174,8 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
     };
     load_w(wv, 0);
     __syncthreads();
-#pragma unroll 1
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + 1 < NKB) load_w(wn, kb + 1);
+    // one 32-channel block with the weights in `wv`; the two register sets alternate (QPWC_W_NEXT_ALWAYS)
+    auto block = [&](f16x8e (&wv)[4], int kb) __attribute__((always_inline)) {
 #if QPWC_UPCONV16_PIPE
         // a tap's TH operand reads go out one tap ahead of its matrix instructions (as in conv3x3_mish_f16_kernel)
         f16x8e bb[2][TH];
@@ -1131,9 +1204,30 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[t], bv, acc[m], 0, 0, 0);
             }
 #endif
+    };
+#if QPWC_W_NEXT_ALWAYS_F16
+    {
+        int kb = 0;
+#pragma unroll 1
+        for (; kb + 1 < NKB; kb += 2) {
+            load_w(wn, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);   // (unfenced, the scheduler sinks the requests to just in front of their use)
+            block(wv, kb);
+            load_w(wv, kb + 2 < NKB ? kb + 2 : kb);   // (last trip: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            block(wn, kb + 1);
+        }
+        if (kb < NKB) block(wv, kb);   // odd number of blocks
+    }
+#else
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+        block(wv, kb);
 #pragma unroll
         for (int t = 0; t < 4; ++t) wv[t] = wn[t];
     }
+#endif
     const int H2 = 2 * H, W2 = 2 * W;
     __half* ob = out + (int64_t)b * H2 * W2 * out_pixel_stride;
     const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
@@ -1422,9 +1516,8 @@ __global__ __launch_bounds__(256, (2 * (2 * TH + 1) * (kEcTW + 1) * CI * 4 > 80 
     };
     load_w(wv, 0);
     __syncthreads();
-#pragma unroll 1
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + 1 < NKB) load_w(wn, kb + 1);
+    // one 32-channel block with the weights in `wv`; the two register sets alternate (QPWC_W_NEXT_ALWAYS)
+    auto block = [&](f32x4e (&wv)[9][2], int kb) __attribute__((always_inline)) {
 #if QPWC_S2_PIPE
         // one step = (tap, 16-channel chunk); the operand reads of step i + 1 go out before the matrix instructions of
         // step i (as in conv3x3_mish_wide_kernel)
@@ -1468,11 +1561,32 @@ __global__ __launch_bounds__(256, (2 * (2 * TH + 1) * (kEcTW + 1) * CI * 4 > 80 
                             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx][kc][t], bv[m][t], acc[m], 0, 0, 0);
                 }
 #endif
+    };
+#if QPWC_W_NEXT_ALWAYS
+    {
+        int kb = 0;
+#pragma unroll 1
+        for (; kb + 1 < NKB; kb += 2) {
+            load_w(wn, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);   // (unfenced, the scheduler sinks the requests to just in front of their use)
+            block(wv, kb);
+            load_w(wv, kb + 2 < NKB ? kb + 2 : kb);   // (last trip: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            block(wn, kb + 1);
+        }
+        if (kb < NKB) block(wv, kb);   // odd number of blocks
+    }
+#else
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+        block(wv, kb);
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) wv[k][kc] = wn[k][kc];
     }
+#endif
     float* ob = out + (int64_t)b * Ho * Wo * CO;
     const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
 #pragma unroll
@@ -1598,9 +1712,8 @@ __global__ __launch_bounds__(256) void conv3x3s2_mish_f16_kernel(const __half* _
     };
     load_w(wv, 0);
     __syncthreads();
-#pragma unroll 1
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + 1 < NKB) load_w(wn, kb + 1);
+    // one 32-channel block with the weights in `wv`; the two register sets alternate (QPWC_W_NEXT_ALWAYS)
+    auto block = [&](f16x8e (&wv)[9], int kb) __attribute__((always_inline)) {
 #if QPWC_S2_16_PIPE
         // operand reads two taps ahead of their matrix instructions (RW of 16 cycles per tap: one tap would not cover
         // the LDS latency)
@@ -1634,9 +1747,30 @@ __global__ __launch_bounds__(256) void conv3x3s2_mish_f16_kernel(const __half* _
             }
         }
 #endif
+    };
+#if QPWC_W_NEXT_ALWAYS_F16
+    {
+        int kb = 0;
+#pragma unroll 1
+        for (; kb + 1 < NKB; kb += 2) {
+            load_w(wn, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);   // (unfenced, the scheduler sinks the requests to just in front of their use)
+            block(wv, kb);
+            load_w(wv, kb + 2 < NKB ? kb + 2 : kb);   // (last trip: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            block(wn, kb + 1);
+        }
+        if (kb < NKB) block(wv, kb);   // odd number of blocks
+    }
+#else
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_w(wn, kb + 1);
+        block(wv, kb);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) wv[tap] = wn[tap];
     }
+#endif
     __half* ob = out + (int64_t)b * Ho * Wo * CO;
     const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
 #pragma unroll
