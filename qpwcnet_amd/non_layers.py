@@ -213,9 +213,27 @@ class UpConv(_Weighted):
                 w.shape[1] % 16 == 0 and tuple(w.shape[2:]) == (4, 4) and skip.shape[3] % 4 == 0 and
                 tuple(skip.shape[1:3]) == (2 * x.shape[1], 2 * x.shape[2]))
 
-    def cat_skip(self, x, skip, batch_chunks=1, hip_chunks=1):
+    def prefill_skip(self, skip, c_in):
+        """The concat([up, skip]) buffer of this level with its SKIP half already copied -- for a caller that has the
+        skip (an encoder feature) long before the decoder input: QpwcNet lays these copies under the encoder's later
+        levels on the side stream instead of beside the coarse flow levels (round 4).  c_in: channels of the decoder
+        input the buffer will be completed from.  None where cat_skip() would not take the HIP path."""
+        w = self.p("conv_up.weight")
+        if not (self.hip_upconv and self.skip_copy_hip and self.data_format == CHANNELS_LAST and skip.is_cuda and
+                skip.dtype in (torch.float32, torch.float16) and c_in in (64, 128, 256) and w.shape[0] == c_in and
+                w.shape[1] % 16 == 0 and tuple(w.shape[2:]) == (4, 4) and skip.shape[3] % 4 == 0):
+            return None
+        buf = torch.empty(skip.shape[:3] + (w.shape[1] + skip.shape[3],), dtype=skip.dtype, device=skip.device)
+        half = buf[..., w.shape[1]:]
+        if not ops.copy_pixels_ok(skip, half):
+            return None
+        ops.copy_pixels(skip, half)
+        return buf
+
+    def cat_skip(self, x, skip, batch_chunks=1, hip_chunks=1, buf=None):
         """concat([UpConv(x), skip]) on the channel axis (pwcnet.py:186-195).  On the HIP path the
-        activation epilogue writes its half straight into the concat buffer."""
+        activation epilogue writes its half straight into the concat buffer.  buf: the buffer from prefill_skip()
+        (skip half already in place; ordering it before this call is the caller's business)."""
         if self._hip_upconv_ok(x, skip):
             # own transposed-convolution kernel: bias + Mish fused, written straight into the concat buffer
             key = self.prefix + ("#taps_up" if x.dtype == torch.float32 else "#taps_up_f16")
@@ -228,7 +246,11 @@ class UpConv(_Weighted):
                 if t3 is None:
                     t3 = self.params[self.prefix + "#taps_up_x3"] = ops.split_bf16x3(t)
                 t = t3
-            buf = torch.empty(skip.shape[:3] + (n_up + skip.shape[3],), dtype=x.dtype, device=x.device)
+            prefilled = buf is not None
+            if prefilled and (tuple(buf.shape) != tuple(skip.shape[:3]) + (n_up + skip.shape[3],) or buf.dtype != x.dtype):
+                raise ValueError("prefilled concat buffer {} does not fit this level".format(tuple(buf.shape)))
+            if not prefilled:
+                buf = torch.empty(skip.shape[:3] + (n_up + skip.shape[3],), dtype=x.dtype, device=x.device)
             nch = int(hip_chunks)
             if nch > 1 and x.shape[0] % nch == 0:
                 nb = x.shape[0] // nch
@@ -237,7 +259,9 @@ class UpConv(_Weighted):
             else:
                 ops.upconv4x4s2_mish_into(x, t, self.p32("conv_up.bias"), buf)
             half = buf[..., n_up:]
-            if self.skip_copy_hip and ops.copy_pixels_ok(skip, half):
+            if prefilled:
+                pass
+            elif self.skip_copy_hip and ops.copy_pixels_ok(skip, half):
                 ops.copy_pixels(skip, half)     # own strided copy instead of the library's elementwise kernel
             else:
                 half.copy_(skip)

@@ -110,6 +110,11 @@ class QpwcNet:
         # round 4 (tools/capture_crosswait.py): the two suspects of the capture SIGSEGV as switches
         self.allow_returning_dec_streams = False    # a mapping like (0,1,0,1): two side streams waiting on each other
         self.record_stream_under_capture = True     # Tensor.record_stream on private-pool tensors while capturing
+        # the skip halves of the decoder's concat buffers copied under the encoder (_prefill): measured SLOWER -- 1.230 vs 1.133
+        # ms/step (config 5: 1.781 vs 1.645; config 4: 30.0 vs 29.8): a fork that early turns the encoder's chain into one branch
+        # of a two-branch graph for its whole length (tools/step_time.py prefill_skips=True).  Off.
+        self.prefill_skips = False
+        self._prefilled = {}
         # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
         # round 3 (tools/step_time.py "dec_chunks=...", three interleaved runs each in one call, ms/step): (2,4,4,4)
         # 1.2147, (2,4,4,2) 1.1996, (2,4,4,1) 1.1991, (2,4,2,2) 1.2005, (2,2,4,1) 1.2031, (2,4,8,8) 1.296: the finest
@@ -188,8 +193,13 @@ class QpwcNet:
             raise ValueError("expected input shape (B,)+{}, got {}".format(exp, tuple(inputs.shape)))
         if self.batch_frames:
             nb = inputs.shape[0]
-            encs = self._encode_stacked(inputs)
-            return self._forward_stacked(encs, nb, self.overlap_streams and inputs.is_cuda)
+            overlap = self.overlap_streams and inputs.is_cuda
+            self._prefilled = {}
+            encs = self._encode_stacked(inputs, prefill=overlap and self.prefill_skips)
+            try:
+                return self._forward_stacked(encs, nb, overlap)
+            finally:
+                self._prefilled = {}
         img_prv, img_nxt = self.split(inputs)
         encs_prv, encs_nxt = encoder(self.enc, img_prv, img_nxt, True)
         decs_prv, decs_nxt = decoder(self.dec, encs_prv, encs_nxt, self.axis, True)
@@ -197,7 +207,32 @@ class QpwcNet:
                       self.data_format, output_multiscale=self.train)
         return outs if self.train else outs[0]
 
-    def _encode_stacked(self, inputs):
+    def _prefill(self, li, f):
+        """Encoder level li (li < 4) is the skip of decoder level 3 - li: allocate that level's concat buffer and copy the
+        skip half NOW, on the decoder's side stream, under the encoder's remaining levels (whose kernels leave the memory
+        system idle) instead of beside the coarse flow levels, where both queues are full (round 4: the four copies are
+        41 us of the second queue's ~310 us in that phase).  The side stream only ever waits for the caller's stream here."""
+        i = len(self.dec) - 1 - li
+        if i < 0 or self.dec_stream_of[i] != 0:
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=f.device)
+        if not self._sides:
+            self._sides.append(self._side)
+        side = self._sides[0]
+        c_in = ENC_FILTERS[-1] if i == 0 else DEC_FILTERS[i - 1] + ENC_FILTERS[-1 - i]   # channels of decoder level i's input
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            buf = self.dec[i].prefill_skip(f, c_in)
+        if buf is not None:
+            if self.record_stream_under_capture or not torch.cuda.is_current_stream_capturing():
+                f.record_stream(side)
+            self._prefilled[i] = buf
+
+    def _encode_stacked(self, inputs, prefill=False):
         """The encoder/decoder weights are shared by both frames (pwcnet.py:145-162, 179-206): run
         the encoder once on the 2B stacked frames [prv; nxt] -> [frames, enc_0 .. enc_4]."""
         h, w = self.input_shape
@@ -222,6 +257,8 @@ class QpwcNet:
             f, padded = l.forward_padded(f, padded, want_padded=li + 1 < len(self.enc),
                                          after_a=first if li == 0 else None)
             encs.append(f)
+            if prefill and li + 1 < len(self.enc):
+                self._prefill(li, f)
         return encs
 
     def _forward_stacked(self, encs, nb, overlap):
@@ -310,7 +347,8 @@ class QpwcNet:
                     side.wait_event(ready[i - 1])       # the previous decoder level ran on another stream
                 with torch.cuda.stream(side):
                     hip_chunks = (self.dec_chunks[i] if small else 1) if tok[0] == "D" else 1
-                    f = self.dec[i].cat_skip(f, encs[k], batch_chunks=chunks if tok[0] == "D" else 1, hip_chunks=hip_chunks)
+                    f = self.dec[i].cat_skip(f, encs[k], batch_chunks=chunks if tok[0] == "D" else 1, hip_chunks=hip_chunks,
+                                             buf=self._prefilled.get(i) if side is sides[0] else None)
                     k -= 1
                     # allocated on `side`, read by UpFlow on `main`: tell the caching allocator, so that the block
                     # is not handed to a later side-stream allocation while main may still be reading it (the
