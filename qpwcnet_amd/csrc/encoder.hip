@@ -118,6 +118,12 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 #ifndef QPWC_ENC_NARROW_EARLY
 #define QPWC_ENC_NARROW_EARLY 0   // A/B (round 4): narrow fp32 kernel, weights (C = 16) + bias requested with the tile's inputs: 32.4 vs 32.3, 30.2 vs 30.3 us, step +-0 -- off
 #endif
+#ifndef QPWC_ENC_WIDE_WAVES
+#define QPWC_ENC_WIDE_WAVES 2   // waves per SIMD the wide fp32 kernel is compiled for (2: 256 registers; 1: the accumulators move to AGPRs, +-0)
+#endif
+#ifndef QPWC_ENC_PIPE_FENCE
+#define QPWC_ENC_PIPE_FENCE 1
+#endif
 #ifndef QPWC_ENC_PIPE
 #define QPWC_ENC_PIPE 1   // operand reads of the wide fp32 kernels issued this many steps ahead (0 = as the compiler places them)
 #endif
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_mish_kernel(const float* __res
 // half the matrix instructions each, one hiding the other's waits.  The sum is (first half) + (second half) instead
 // of one chain: another fp32 rounding order of the same products.
 template <int C, int TH, int KS = 1>
-__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_mish_wide_kernel(
+__global__ __launch_bounds__(256 * KS, KS == 1 ? QPWC_ENC_WIDE_WAVES : 1) void conv3x3_mish_wide_kernel(
     const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int pad_h, int pad_w, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int NT = 256 * KS;                   // threads
@@ -411,6 +417,10 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_mish_wide_k
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             if (i + RD < 18) read_b(bb[(i + RD) % (RD + 1)], i + RD);
+            // (round 4: without this fence the scheduler sinks the reads to the END of the step, into the registers the step
+            // has just finished with: one buffer, the reads three matrix instructions ahead of their use.  Fenced, a true
+            // step ahead: C = 64 27.9-28.6 vs 29.5-29.7 us, C = 128 +1 %, C = 256 29.0-29.7 vs 28.4-28.6 -- C = 64 only)
+            if (QPWC_ENC_PIPE_FENCE && C == 64) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
