@@ -114,6 +114,7 @@ class QpwcNet:
         # ms/step (config 5: 1.781 vs 1.645; config 4: 30.0 vs 29.8): a fork that early turns the encoder's chain into one branch
         # of a two-branch graph for its whole length (tools/step_time.py prefill_skips=True).  Off.
         self.prefill_skips = False
+        self.skip_copy_first = (3, 2)    # see _forward_two_streams
         self._prefilled = {}
         # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
         # round 3 (tools/step_time.py "dec_chunks=...", three interleaved runs each in one call, ms/step): (2,4,4,4)
@@ -334,6 +335,20 @@ class QpwcNet:
         # (decoder levels 0-2: ~200 us alone; flow levels 0-2: ~200 us alone) share the chip for ~300 us whatever the
         # order; the default order stays.
         order = self.capture_order
+        # Round 4: the skip halves of the finest decoder levels' concat buffers are copied FIRST on the side stream -- beside
+        # the coarsest flow level, whose launches leave the chip almost empty -- instead of after their level's transposed
+        # convolution, beside flow levels 2 and 3 where both queues are full (skip_copy_first: decoder levels, in this order)
+        for i in self.skip_copy_first:
+            if i in self._prefilled or not 0 <= i < len(self.dec) or ("D%d" % i) not in order:
+                continue
+            side = sides[self.dec_stream_of[i]]
+            if side is not sides[0]:
+                continue
+            c_in = ENC_FILTERS[-1] if i == 0 else DEC_FILTERS[i - 1] + ENC_FILTERS[-1 - i]
+            with torch.cuda.stream(side):
+                buf = self.dec[i].prefill_skip(encs[-2 - i], c_in)
+            if buf is not None:
+                self._prefilled[i] = buf
         ready, decs, flos, ran_on = {}, {}, [], {}
         waited_on_main = set()      # decoder levels whose `ready` event the caller's stream has waited for
         f, k, flo = encs[-1], -2, None

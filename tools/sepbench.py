@@ -41,12 +41,15 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--levels", default="2,3,4")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--res", default="256x512", help="input resolution the level shapes derive from (1024x2048: config 4)")
+    ap.add_argument("--fused-only", action="store_true")
     a = ap.parse_args()
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
     chans = [256, 256, 128, 64, 32]
     for l in map(int, a.levels.split(",")):
-        H, W, Cf = 256 >> (5 - l), 512 >> (5 - l), chans[l]
+        rh, rw = (int(v) for v in a.res.split("x"))
+        H, W, Cf = rh >> (5 - l), rw >> (5 - l), chans[l]
         B = a.batch
         layers = [((81, Cf, 2) if l > 0 else (81, Cf, Cf), 128), ((128,), 64), ((64,), 32), ((32,), 16)]
         for li, (src_ch, F) in enumerate(layers):
@@ -75,9 +78,12 @@ def main():
                 y = ops.dwconv3x3(srcs, dw, mish_on_load=act)
                 return torch.addmm(bias, y.view(B * H * W, -1), pwt)
 
-            chk = ops.sepconv3x3(fsrcs, fdw, fpwp, bias, mish_on_load=act)
-            err = float((chk.view(B * H * W, -1) - split()).abs().max())
-            tf, ts = timeit(fused, a.iters), timeit(split, a.iters)
+            if a.fused_only:
+                err, tf, ts = float("nan"), timeit(fused, a.iters), float("nan")
+            else:
+                chk = ops.sepconv3x3(fsrcs, fdw, fpwp, bias, mish_on_load=act)
+                err = float((chk.view(B * H * W, -1) - split()).abs().max())
+                tf, ts = timeit(fused, a.iters), timeit(split, a.iters)
             flops = 2.0 * B * H * W * C * (F + 9)
             print("L%d layer %d  %dx%dx%d  C %3d -> F %3d : fused %7.1f us (%5.1f TF)   dw+gemm %7.1f us   max|diff| %.1e"
                   % (l, li + 1, B, H, W, C, F, tf, flops / tf * 1e-6, ts, err), flush=True)
