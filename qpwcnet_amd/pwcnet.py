@@ -114,7 +114,7 @@ class QpwcNet:
         # ms/step (config 5: 1.781 vs 1.645; config 4: 30.0 vs 29.8): a fork that early turns the encoder's chain into one branch
         # of a two-branch graph for its whole length (tools/step_time.py prefill_skips=True).  Off.
         self.prefill_skips = False
-        self.skip_copy_first = (3, 2)    # see _forward_two_streams
+        self.skip_copy_first = ()    # see _forward_two_streams: (3, 2) 1.140-1.145, (3,) 1.138-1.140, (3, 2, 1, 0) 1.142-1.145 vs () 1.130-1.133 ms/step
         self._prefilled = {}
         # launches per decoder level on the side stream (slices of the 2B stacked frames), see _forward_two_streams
         # round 3 (tools/step_time.py "dec_chunks=...", three interleaved runs each in one call, ms/step): (2,4,4,4)
@@ -337,7 +337,8 @@ class QpwcNet:
         order = self.capture_order
         # Round 4: the skip halves of the finest decoder levels' concat buffers are copied FIRST on the side stream -- beside
         # the coarsest flow level, whose launches leave the chip almost empty -- instead of after their level's transposed
-        # convolution, beside flow levels 2 and 3 where both queues are full (skip_copy_first: decoder levels, in this order)
+        # convolution, beside flow levels 2 and 3 where both queues are full (skip_copy_first: decoder levels, in this order).
+        # Measured slower in every order tried (the decoder's first level is then late for flow level 1): off.
         for i in self.skip_copy_first:
             if i in self._prefilled or not 0 <= i < len(self.dec) or ("D%d" % i) not in order:
                 continue
