@@ -385,6 +385,19 @@ int qpwc_upconv4x4s2_mish_x3_fwd(const void* x, const void* weight3, const void*
 int qpwc_upconv4x4s2_mish_f16_fwd(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                                   int C, int F, int64_t out_pixel_stride, void* stream);
 
+/* qpwc_upconv4x4s2_mish_fwd AND the skip half of the decoder's concat([up, skip]) (pwcnet.py:186-195) in one launch:
+ * channels [0, F) of `out` as there, and channels [F, 2F) = the first F channels of `skip` (B, 2H, 2W, >= F), whose batch /
+ * row / pixel strides are given in elements (multiples of 4; the skip may be the interior of a zero-bordered buffer).
+ * out_pixel_stride >= 2F; out must not overlap x or skip.  fp32: every pointer 16-byte aligned. */
+int qpwc_upconv4x4s2_mish_cat_fwd(const void* x, const void* weight, const void* bias, const void* skip,
+                                  int64_t skip_batch_stride, int64_t skip_row_stride, int64_t skip_pixel_stride, void* out,
+                                  int B, int H, int W, int C, int F, int64_t out_pixel_stride, void* stream);
+
+/* The same for fp16 storage: x, weight, skip and out fp16 (out, skip 8-byte aligned), bias fp32. */
+int qpwc_upconv4x4s2_mish_cat_f16_fwd(const void* x, const void* weight, const void* bias, const void* skip,
+                                      int64_t skip_batch_stride, int64_t skip_row_stride, int64_t skip_pixel_stride, void* out,
+                                      int B, int H, int W, int C, int F, int64_t out_pixel_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ SYMBOLS = (
     "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd", "qpwc_epe_multi_mixed_fwd",
     "qpwc_cost_volume_to_flow_fwd", "qpwc_sepconv3x3_fwd", "qpwc_sepconv3x3_f16_fwd", "qpwc_bias_mish_pad_fwd", "qpwc_split_frames_pad_fwd",
     "qpwc_invert_flow_fwd", "qpwc_occlusion_fwd", "qpwc_conv3x3_mish_fwd", "qpwc_conv3x3_mish_f16_fwd", "qpwc_conv3x3_mish_x3_fwd", "qpwc_split_bf16x3_fwd", "qpwc_sepconv3x3_x3_fwd", "qpwc_conv3x3s2_mish_x3_fwd", "qpwc_upconv4x4s2_mish_x3_fwd",
-    "qpwc_first_conv_mish_fwd", "qpwc_first_conv_mish_f16_fwd", "qpwc_conv3x3s2_mish_fwd", "qpwc_conv3x3s2_mish_c_fwd", "qpwc_conv3x3s2_mish_f16_fwd", "qpwc_upconv4x4s2_mish_fwd", "qpwc_upconv4x4s2_mish_f16_fwd",
+    "qpwc_first_conv_mish_fwd", "qpwc_first_conv_mish_f16_fwd", "qpwc_conv3x3s2_mish_fwd", "qpwc_conv3x3s2_mish_c_fwd", "qpwc_conv3x3s2_mish_f16_fwd", "qpwc_upconv4x4s2_mish_fwd", "qpwc_upconv4x4s2_mish_f16_fwd", "qpwc_upconv4x4s2_mish_cat_fwd", "qpwc_upconv4x4s2_mish_cat_f16_fwd",
 )
 
 _lib = None
@@ -158,6 +158,10 @@ def lib():
     L.qpwc_upconv4x4s2_mish_x3_fwd.argtypes = L.qpwc_upconv4x4s2_mish_fwd.argtypes
     L.qpwc_upconv4x4s2_mish_x3_fwd.restype = ci
     L.qpwc_upconv4x4s2_mish_f16_fwd.restype = ci
+    L.qpwc_upconv4x4s2_mish_cat_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, ci, ci, ci, ci, ci, i64, vp]
+    L.qpwc_upconv4x4s2_mish_cat_fwd.restype = ci
+    L.qpwc_upconv4x4s2_mish_cat_f16_fwd.argtypes = L.qpwc_upconv4x4s2_mish_cat_fwd.argtypes
+    L.qpwc_upconv4x4s2_mish_cat_f16_fwd.restype = ci
     _lib = L
     return L
 

@@ -75,9 +75,11 @@ int invert_flow_launch(const void* flow, void* out, int B, int H, int W, int lay
 int occlusion_launch(const void* flow, void* out, int B, int H, int W, int layout, int dtype,
                      hipStream_t s);
 int upconv4x4s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int C,
-                            int F, int out_pixel_stride, hipStream_t s);
+                            int F, int out_pixel_stride, hipStream_t s, const void* skip = nullptr, int64_t skip_bs = 0,
+                            int64_t skip_rs = 0, int64_t skip_ps = 0);
 int upconv4x4s2_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int C,
-                            int F, int out_pixel_stride, hipStream_t s);
+                            int F, int out_pixel_stride, hipStream_t s, const void* skip = nullptr, int64_t skip_bs = 0,
+                            int64_t skip_rs = 0, int64_t skip_ps = 0);
 int conv3x3s2_mish_any_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                               int CI, hipStream_t s);
 int conv3x3s2_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
@@ -806,6 +808,47 @@ int qpwc_upconv4x4s2_mish_f16_fwd(const void* x, const void* weight, const void*
     if (overlaps(out, (size_t)B * 4 * H * W * out_pixel_stride * 2, x, (size_t)B * H * W * C * 2))
         return fail(QPWC_E_ALIAS, "out overlaps x");
     return upconv4x4s2_mish_f16_launch(x, weight, bias, out, B, H, W, C, F, (int)out_pixel_stride, (hipStream_t)stream);
+}
+
+// UpConv + the skip half of concat([up, skip]) in one launch (round 4; include/qpwc.h)
+static int upconv_cat_common(const void* x, const void* weight, const void* bias, const void* skip, int64_t skip_bs,
+                             int64_t skip_rs, int64_t skip_ps, void* out, int B, int H, int W, int C, int F,
+                             int64_t out_pixel_stride, void* stream, int esize) {
+    if (!x || !weight || !bias || !out || !skip) return fail(QPWC_E_NULL, "null pointer argument");
+    if (C != 64 && C != 128 && C != 256) return fail(QPWC_E_SHAPE, "C=%d not in {64,128,256}", C);
+    if (F <= 0 || F % 16) return fail(QPWC_E_SHAPE, "F=%d must be a positive multiple of 16", F);
+    if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
+    if (out_pixel_stride < 2 * (int64_t)F || out_pixel_stride % 4 || out_pixel_stride > (1 << 20))
+        return fail(QPWC_E_STRIDE, "out_pixel_stride %lld must be >= 2 F and a multiple of 4", (long long)out_pixel_stride);
+    if (skip_ps < F || skip_ps % 4 || skip_rs % 4 || skip_bs % 4 || skip_rs < 2 * (int64_t)W * skip_ps ||
+        skip_bs < 2 * (int64_t)H * skip_rs)
+        return fail(QPWC_E_STRIDE, "skip strides (%lld, %lld, %lld) must describe (B, 2H, 2W, >= F) in multiples of 4 elements",
+                    (long long)skip_bs, (long long)skip_rs, (long long)skip_ps);
+    const int oa = esize == 4 ? 16 : 8;
+    if ((uintptr_t)x % 16 || (uintptr_t)weight % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % oa || (uintptr_t)skip % oa)
+        return fail(QPWC_E_ALIGN, "x, weight, bias must be 16-byte aligned, out and skip %d-byte", oa);
+    const size_t out_bytes = (size_t)B * 4 * H * W * out_pixel_stride * esize;
+    if (overlaps(out, out_bytes, x, (size_t)B * H * W * C * esize)) return fail(QPWC_E_ALIAS, "out overlaps x");
+    if (overlaps(out, out_bytes, skip, (size_t)B * skip_bs * esize)) return fail(QPWC_E_ALIAS, "out overlaps skip");
+    if (esize == 4)
+        return upconv4x4s2_mish_launch(x, weight, bias, out, B, H, W, C, F, (int)out_pixel_stride, (hipStream_t)stream, skip,
+                                       skip_bs, skip_rs, skip_ps);
+    return upconv4x4s2_mish_f16_launch(x, weight, bias, out, B, H, W, C, F, (int)out_pixel_stride, (hipStream_t)stream, skip,
+                                       skip_bs, skip_rs, skip_ps);
+}
+
+int qpwc_upconv4x4s2_mish_cat_fwd(const void* x, const void* weight, const void* bias, const void* skip,
+                                  int64_t skip_batch_stride, int64_t skip_row_stride, int64_t skip_pixel_stride, void* out,
+                                  int B, int H, int W, int C, int F, int64_t out_pixel_stride, void* stream) {
+    return upconv_cat_common(x, weight, bias, skip, skip_batch_stride, skip_row_stride, skip_pixel_stride, out, B, H, W, C, F,
+                             out_pixel_stride, stream, 4);
+}
+
+int qpwc_upconv4x4s2_mish_cat_f16_fwd(const void* x, const void* weight, const void* bias, const void* skip,
+                                      int64_t skip_batch_stride, int64_t skip_row_stride, int64_t skip_pixel_stride, void* out,
+                                      int B, int H, int W, int C, int F, int64_t out_pixel_stride, void* stream) {
+    return upconv_cat_common(x, weight, bias, skip, skip_batch_stride, skip_row_stride, skip_pixel_stride, out, B, H, W, C, F,
+                             out_pixel_stride, stream, 2);
 }
 
 }  // extern "C"

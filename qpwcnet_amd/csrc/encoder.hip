@@ -961,13 +961,22 @@ int conv3x3_mish_f16_launch(const void* x, const void* weight, const void* bias,
 // (Resident workgroups walking the tiles behind a capped grid: 1.294 ms/step at 256, 1.262 at 384 workgroups,
 // against 1.257 for four plain launches over quarters of the batch -- see UpConv.cat_skip.)
 // weight: [ky*4+kx][F][C] fp32.
+// Round 4: the SKIP half of the decoder's concat([up, skip]) copied by the same launch (qpwc_upconv4x4s2_mish_cat_fwd):
+// lane (pixel n, quad g) of output block fo also moves channels fo + 4g .. + 3 of its output pixels from `skip` to channels
+// [F, 2F) of `out` -- F skip channels, the decoder's case at every level -- instead of a separate qpwc_copy_pixels launch
+// beside the flow levels (four launches, 41 us of the second queue per step).  p == nullptr: no copy.
+struct UpSkip {
+    const void* p;
+    long long bs, rs, ps;   // batch / row / pixel stride of the skip tensor, elements
+};
+
 template <int C, int TH>
 __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ weight,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out, int H, int W, int F,
                                                                   int out_pixel_stride, int tiles_x, int tiles_y,
-                                                                  int n_tiles) {
+                                                                  int n_tiles, UpSkip skip) {
     constexpr int NQ = C / 4, NKB = C / 32;
     constexpr int HH = TH + 2, NH = HH * kEcHW;
     constexpr int NST = (NH * NQ + 255) / 256;
@@ -1089,20 +1098,36 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_kernel(const float* _
     }
     const int H2 = 2 * H, W2 = 2 * W;
     float* ob = out + (int64_t)b * H2 * W2 * out_pixel_stride;
+    // the skip values of this lane's output pixels: requested before the bias, stored behind the outputs
+    const float* sk = reinterpret_cast<const float*>(skip.p);
+    float4 sv[TH];
+    if (sk != nullptr) {
+#pragma unroll
+        for (int m = 0; m < TH; ++m) {
+            const int gy = Y0 + m, gx = X0 + n;
+            sv[m] = (gy < H && gx < W)
+                        ? *reinterpret_cast<const float4*>(sk + b * skip.bs + (int64_t)(2 * gy + py) * skip.rs +
+                                                           (int64_t)(2 * gx + px) * skip.ps + fo + 4 * g)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
 #pragma unroll
     for (int m = 0; m < TH; ++m) {
         const int gy = Y0 + m, gx = X0 + n;
-        if (gy < H && gx < W)
-            *reinterpret_cast<float4*>(ob + ((int64_t)(2 * gy + py) * W2 + 2 * gx + px) * out_pixel_stride + fo + 4 * g) =
+        if (gy < H && gx < W) {
+            float* op = ob + ((int64_t)(2 * gy + py) * W2 + 2 * gx + px) * out_pixel_stride + fo + 4 * g;
+            *reinterpret_cast<float4*>(op) =
                 make_float4(enc_mishf(acc[m][0] + bq.x), enc_mishf(acc[m][1] + bq.y),
                             enc_mishf(acc[m][2] + bq.z), enc_mishf(acc[m][3] + bq.w));
+            if (sk != nullptr) *reinterpret_cast<float4*>(op + F) = sv[m];
+        }
     }
 }
 
 template <int C, int TH>
 static int upconv_launch_t(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int F,
-                           int out_pixel_stride, hipStream_t s) {
+                           int out_pixel_stride, hipStream_t s, UpSkip skip) {
     const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + TH - 1) / TH;
     const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
     if (n_tiles * (F / 16) > INT32_MAX) {
@@ -1111,16 +1136,18 @@ static int upconv_launch_t(const void* x, const void* weight, const void* bias, 
     }
     hipLaunchKernelGGL((upconv4x4s2_mish_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), 0, s,
                        (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, F,
-                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles);
+                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles, skip);
     return check_launch("upconv4x4s2_mish_kernel");
 }
 
 int upconv4x4s2_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int C,
-                            int F, int out_pixel_stride, hipStream_t s) {
+                            int F, int out_pixel_stride, hipStream_t s, const void* skip, int64_t skip_bs, int64_t skip_rs,
+                            int64_t skip_ps) {
+    const UpSkip sk{skip, (long long)skip_bs, (long long)skip_rs, (long long)skip_ps};
     switch (C) {
-        case 64: return upconv_launch_t<64, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
-        case 128: return upconv_launch_t<128, 4>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
-        case 256: return upconv_launch_t<256, 2>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 64: return upconv_launch_t<64, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
+        case 128: return upconv_launch_t<128, 4>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
+        case 256: return upconv_launch_t<256, 2>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
         default: set_error("upconv4x4s2_mish: C=%d not in {64,128,256}", C); return QPWC_E_SHAPE;
     }
 }
@@ -1135,7 +1162,7 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
                                                                       const float* __restrict__ bias,
                                                                       __half* __restrict__ out, int H, int W, int F,
                                                                       int out_pixel_stride, int tiles_x, int tiles_y,
-                                                                      int n_tiles) {
+                                                                      int n_tiles, UpSkip skip) {
     constexpr int NQ = C / 8, NKB = C / 32;
     constexpr int HH = TH + 2, NH = HH * kEcHW;
     constexpr int NST = (NH * NQ + 255) / 256;
@@ -1240,6 +1267,18 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
 #endif
     const int H2 = 2 * H, W2 = 2 * W;
     __half* ob = out + (int64_t)b * H2 * W2 * out_pixel_stride;
+    const __half* sk = reinterpret_cast<const __half*>(skip.p);   // (see upconv4x4s2_mish_kernel)
+    f16x4e sv[TH];
+    if (sk != nullptr) {
+#pragma unroll
+        for (int m = 0; m < TH; ++m) {
+            const int gy = Y0 + m, gx = X0 + n;
+            sv[m] = (gy < H && gx < W)
+                        ? *reinterpret_cast<const f16x4e*>(sk + b * skip.bs + (int64_t)(2 * gy + py) * skip.rs +
+                                                           (int64_t)(2 * gx + px) * skip.ps + fo + 4 * g)
+                        : f16x4e{0, 0, 0, 0};
+        }
+    }
     const float4 bq = *reinterpret_cast<const float4*>(bias + fo + 4 * g);
 #pragma unroll
     for (int m = 0; m < TH; ++m) {
@@ -1250,14 +1289,16 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
             o[1] = (_Float16)enc_mishf(acc[m][1] + bq.y);
             o[2] = (_Float16)enc_mishf(acc[m][2] + bq.z);
             o[3] = (_Float16)enc_mishf(acc[m][3] + bq.w);
-            *reinterpret_cast<f16x4e*>(ob + ((int64_t)(2 * gy + py) * W2 + 2 * gx + px) * out_pixel_stride + fo + 4 * g) = o;
+            __half* op = ob + ((int64_t)(2 * gy + py) * W2 + 2 * gx + px) * out_pixel_stride + fo + 4 * g;
+            *reinterpret_cast<f16x4e*>(op) = o;
+            if (sk != nullptr) *reinterpret_cast<f16x4e*>(op + F) = sv[m];
         }
     }
 }
 
 template <int C, int TH>
 static int upconv_f16_launch_t(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W, int F,
-                               int out_pixel_stride, hipStream_t s) {
+                               int out_pixel_stride, hipStream_t s, UpSkip skip) {
     const int tiles_x = (W + kEcTW - 1) / kEcTW, tiles_y = (H + TH - 1) / TH;
     const int64_t n_tiles = (int64_t)tiles_x * tiles_y * B;
     if (n_tiles * (F / 16) > INT32_MAX) {
@@ -1266,16 +1307,18 @@ static int upconv_f16_launch_t(const void* x, const void* weight, const void* bi
     }
     hipLaunchKernelGGL((upconv4x4s2_mish_f16_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), 0, s,
                        (const __half*)x, (const __half*)weight, (const float*)bias, (__half*)out, H, W, F,
-                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles);
+                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles, skip);
     return check_launch("upconv4x4s2_mish_f16_kernel");
 }
 
 int upconv4x4s2_mish_f16_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
-                                int C, int F, int out_pixel_stride, hipStream_t s) {
+                                int C, int F, int out_pixel_stride, hipStream_t s, const void* skip, int64_t skip_bs,
+                                int64_t skip_rs, int64_t skip_ps) {
+    const UpSkip sk{skip, (long long)skip_bs, (long long)skip_rs, (long long)skip_ps};
     switch (C) {
-        case 64: return upconv_f16_launch_t<64, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
-        case 128: return upconv_f16_launch_t<128, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
-        case 256: return upconv_f16_launch_t<256, 4>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s);
+        case 64: return upconv_f16_launch_t<64, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
+        case 128: return upconv_f16_launch_t<128, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
+        case 256: return upconv_f16_launch_t<256, 4>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
         default: set_error("upconv4x4s2_mish_f16: C=%d not in {64,128,256}", C); return QPWC_E_SHAPE;
     }
 }

@@ -198,6 +198,7 @@ class UpConv(_Weighted):
     # (tools/skipcopy_ab.py: 1.198 vs 1.195 ms/step); round 3: the own kernel is the default, so that the only
     # library launches left on a forward are the two wide pointwise GEMMs of L0 / L1
     skip_copy_hip = True
+    fuse_skip_copy = True   # ... and since round 4 by the transposed convolution's own launch where the skip has F channels
     matmul = "f32"      # "bf16x3": the transposed convolution's products as three-way bf16 splits (csrc/split_bf16.h)
     # ... for the input widths where that moves the STEP (tools/step_time.py, one call, ms/step with every other bf16x3
     # kernel on): decoder on the fp32 instructions 1.0935; all four levels split 1.0941; the three coarse levels only
@@ -252,14 +253,22 @@ class UpConv(_Weighted):
             if not prefilled:
                 buf = torch.empty(skip.shape[:3] + (n_up + skip.shape[3],), dtype=x.dtype, device=x.device)
             nch = int(hip_chunks)
+            # round 4: the skip half copied by the transposed convolution's own launches (qpwc_upconv4x4s2_mish_cat_fwd)
+            cat = (self.fuse_skip_copy and not prefilled and t.dim() == 3 and ops.upconv_cat_ok(x, t, skip, buf))
             if nch > 1 and x.shape[0] % nch == 0:
                 nb = x.shape[0] // nch
                 for i in range(nch):
-                    ops.upconv4x4s2_mish_into(x[i * nb:(i + 1) * nb], t, self.p32("conv_up.bias"), buf[i * nb:(i + 1) * nb])
+                    sl = slice(i * nb, (i + 1) * nb)
+                    if cat:
+                        ops.upconv4x4s2_mish_cat_into(x[sl], t, self.p32("conv_up.bias"), skip[sl], buf[sl])
+                    else:
+                        ops.upconv4x4s2_mish_into(x[sl], t, self.p32("conv_up.bias"), buf[sl])
+            elif cat:
+                ops.upconv4x4s2_mish_cat_into(x, t, self.p32("conv_up.bias"), skip, buf)
             else:
                 ops.upconv4x4s2_mish_into(x, t, self.p32("conv_up.bias"), buf)
             half = buf[..., n_up:]
-            if prefilled:
+            if prefilled or cat:
                 pass
             elif self.skip_copy_hip and ops.copy_pixels_ok(skip, half):
                 ops.copy_pixels(skip, half)     # own strided copy instead of the library's elementwise kernel

@@ -846,6 +846,44 @@ def upconv4x4s2_mish_into(x_nhwc, taps, bias, dst):
     return dst
 
 
+def upconv_cat_ok(x_nhwc, taps, skip, dst):
+    """Can upconv4x4s2_mish_cat_into() take these?  (F skip channels, 4-element-aligned strides, plain fp32 / fp16 taps)"""
+    if taps.dim() != 3 or skip.dim() != 4 or dst.dim() != 4:
+        return False
+    F_ = taps.shape[1]
+    st = skip.stride()
+    esz = 16 // skip.element_size()           # elements per 16 bytes (fp32: 4) -- pointers: 16 B (fp32) / 8 B (fp16)
+    return (skip.is_cuda and skip.dtype == x_nhwc.dtype == dst.dtype == taps.dtype and skip.shape[3] == F_ and
+            dst.shape[3] >= 2 * F_ and st[3] == 1 and st[2] % 4 == 0 and st[1] % 4 == 0 and st[0] % 4 == 0 and
+            st[2] >= F_ and st[1] >= skip.shape[2] * st[2] and st[0] >= skip.shape[1] * st[1] and
+            skip.data_ptr() % (4 * skip.element_size()) == 0 and esz in (4, 8))
+
+
+def upconv4x4s2_mish_cat_into(x_nhwc, taps, bias, skip, dst):
+    """upconv4x4s2_mish_into() AND the skip half of the decoder's concat in the same launch: channels [0, F) of dst =
+    Mish(Conv2DTranspose(x) + bias), channels [F, 2F) = skip (B, 2H, 2W, F; any 4-element-aligned strides, e.g. the interior
+    of a zero-bordered encoder buffer) -- concat([UpConv(x), skip]) of pwcnet.py:186-195 without a separate copy launch."""
+    _check_tensor("x", x_nhwc)
+    _check_tensor("dst", dst)
+    _check_tensor("skip", skip)
+    B, H, W, C = x_nhwc.shape
+    F_ = taps.shape[-2]
+    if x_nhwc.dtype not in (torch.float32, torch.float16) or not x_nhwc.is_contiguous() or not dst.is_contiguous():
+        raise ValueError("upconv4x4s2_mish_cat_into needs dense fp32 / fp16 channels-last x and dst")
+    if tuple(taps.shape) != (16, F_, C) or not taps.is_contiguous() or bias.numel() != F_ or bias.dtype != torch.float32:
+        raise ValueError("taps must be (16,F,{}) of the input's dtype, bias fp32 (F)".format(C))
+    if tuple(dst.shape[:3]) != (B, 2 * H, 2 * W) or tuple(skip.shape) != (B, 2 * H, 2 * W, F_) or not upconv_cat_ok(x_nhwc, taps, skip, dst):
+        raise ValueError("dst must be (B,2H,2W,>=2F), skip (B,2H,2W,F) of the same dtype with 4-element-aligned strides")
+    f16 = x_nhwc.dtype == torch.float16
+    fn = _hip.lib().qpwc_upconv4x4s2_mish_cat_f16_fwd if f16 else _hip.lib().qpwc_upconv4x4s2_mish_cat_fwd
+    st = skip.stride()
+    with torch.cuda.device(dst.device), _timed("upconv4x4s2_mish_f16" if f16 else "upconv4x4s2_mish", (B, H, W, C, F_)):
+        rc = fn(x_nhwc.data_ptr(), taps.data_ptr(), bias.data_ptr(), skip.data_ptr(), st[0], st[1], st[2], dst.data_ptr(),
+                B, H, W, C, F_, dst.shape[3], _stream(dst))
+    _hip.check(rc)
+    return dst
+
+
 def bias_mish_pad(x_nhwc, bias, pad_h, pad_w):
     """Mish(x + bias) written into a new (B, H+pad_h, W+pad_w, C) tensor whose border is zero:
     the activation epilogue and TensorFlow's 'SAME' padding of the following stride-2 conv

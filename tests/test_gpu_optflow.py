@@ -419,6 +419,41 @@ def test_upconv4x4s2_mish_fp16_storage(C, F, hw):
     assert bool((dst[..., F:] == 7.0).all())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C,F", [(64, 16), (128, 32), (256, 64), (256, 128)])
+@pytest.mark.parametrize("hw", [(8, 16), (19, 37), (5, 9)])
+def test_upconv4x4s2_mish_cat_is_upconv_plus_skip_copy(C, F, hw, dtype):
+    """qpwc_upconv4x4s2_mish_cat_fwd (round 4): concat([UpConv(x), skip]) in ONE launch -- bit for bit the transposed
+    convolution's own launch plus a copy of the skip, with the skip read through strides (the interior of a zero-bordered
+    encoder buffer, as the network hands it over), ragged sizes, both storage types; channels past 2F stay untouched."""
+    rng = np.random.default_rng(C + F + hw[0] + 11)
+    H, W = hw
+    B = 3
+    x = _rand(rng, B, H, W, C).to(dtype).to(DEV)
+    w = (_rand(rng, C, F, 4, 4) / np.sqrt(4 * C)).to(DEV)
+    b = _rand(rng, F).to(DEV)
+    taps = ops.upconv_taps(w, dtype)
+    padded = torch.zeros(B, 2 * H + 1, 2 * W + 1, F, device=DEV, dtype=dtype)
+    padded[:, :2 * H, :2 * W] = _rand(rng, B, 2 * H, 2 * W, F).to(dtype).to(DEV)
+    skip = padded[:, :2 * H, :2 * W, :]                       # strides ((2H+1)(2W+1)F, (2W+1)F, F, 1)
+    want = torch.full((B, 2 * H, 2 * W, 2 * F + 8), 7.0, device=DEV, dtype=dtype)
+    ops.upconv4x4s2_mish_into(x, taps, b, want)
+    want[..., F:2 * F] = skip
+    got = torch.full_like(want, 7.0)
+    assert ops.upconv_cat_ok(x, taps, skip, got)
+    ops.upconv4x4s2_mish_cat_into(x, taps, b, skip, got)
+    assert torch.equal(got, want)
+    # a slice of the batch (the decoder's chunked launches) into the matching slice of the buffer
+    got2 = torch.full_like(want, 7.0)
+    for sl in (slice(0, 1), slice(1, 3)):
+        ops.upconv4x4s2_mish_cat_into(x[sl], taps, b, skip[sl], got2[sl])
+    assert torch.equal(got2, want)
+    # refused: a skip with another channel count, a destination too narrow for both halves
+    assert not ops.upconv_cat_ok(x, taps, skip[..., :F - 4], got)
+    with pytest.raises(ValueError):
+        ops.upconv4x4s2_mish_cat_into(x, taps, b, skip, got[..., :2 * F - 4].contiguous())
+
+
 def test_split_frames_pad():
     rng = np.random.default_rng(8)
     x = _rand(rng, 3, 10, 12, 6)
