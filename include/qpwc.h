@@ -249,6 +249,12 @@ int qpwc_flow_head_param_floats(void);
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W,
                        float scale, int dtype, int out_layout, void* stream);
 
+/* qpwc_flow_head_fwd (channels-last) AND the Upsample(scale = up_scale) that follows it in pwcnet.py:55,60 in one launch:
+ * out (B,H,W,2) as there, out_up (B,2H,2W,2) = up_scale * UpSampling2D(2, 'bilinear')(out) -- bit for bit what
+ * qpwc_upsample2x_flow_fwd returns for `out` (the tile's one-pixel rim is computed by the same workgroup). */
+int qpwc_flow_head_up_fwd(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
+                          float up_scale, int dtype, void* stream);
+
 /* The tail of OptFlow.__call__ in one launch, for small images (coarse pyramid levels), fp32 channels-last:
  *   z3   = Mish(SeparableConv2D_3(z2))    64 -> 32   (non_layers.py:223-231, third of the four)
  *   z4   = SeparableConv2D_4(z3)          32 -> 16

@@ -61,6 +61,8 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      int dtype, int out_layout, hipStream_t s);
 int flow_head_param_floats();
+int flow_head_up_launch(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
+                        float up_scale, int dtype, hipStream_t s);
 int optflow_tail_launch(const void* z2, const void* dw3, const void* pw3, const void* b3, const void* dw4,
                         const void* pw4, const void* b4, const void* head, void* out, int B, int H, int W,
                         float scale, int act_in, int out_layout, hipStream_t s);
@@ -456,6 +458,21 @@ int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels, con
 }
 
 int qpwc_flow_head_param_floats(void) { return flow_head_param_floats(); }
+
+int qpwc_flow_head_up_fwd(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
+                          float up_scale, int dtype, void* stream) {
+    if (!z || !params || !out || !out_up) return fail(QPWC_E_NULL, "null pointer argument");
+    if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
+    const size_t es = esize(dtype);
+    if (B <= 0 || H <= 0 || W <= 0) return fail(QPWC_E_SHAPE, "non-positive extent B=%d H=%d W=%d", B, H, W);
+    if ((int64_t)B * 4 * H * W * 2 >= INT32_MAX) return fail(QPWC_E_SHAPE, "upsampled flow too large for 32-bit pixel indices");
+    if ((uintptr_t)z % (4 * es) || (uintptr_t)out % (2 * es) || (uintptr_t)out_up % (4 * es) || (uintptr_t)params % 4)
+        return fail(QPWC_E_ALIGN, "z and out_up must be aligned to 4 elements, out to 2");
+    const size_t nz = (size_t)B * H * W * 16 * es, no = (size_t)B * H * W * 2 * es, nu = 4 * no;
+    if (overlaps(out, no, z, nz) || overlaps(out_up, nu, z, nz) || overlaps(out_up, nu, out, no))
+        return fail(QPWC_E_ALIAS, "out / out_up overlap z or each other");
+    return flow_head_up_launch(z, params, out, out_up, B, H, W, scale, up_scale, dtype, (hipStream_t)stream);
+}
 
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                        int dtype, int out_layout, void* stream) {

@@ -1639,6 +1639,168 @@ int optflow_tail_launch(const void* z2, const void* dw3, const void* pw3, const 
 
 int flow_head_param_floats() { return kFhParams; }
 
+// ---------------------------------------------------------------------------
+// flow head + the Upsample(x2) that always follows it (pwcnet.py:55,60), one launch (round 4): the 16 x 16 flow tile is
+// computed WITH the one-pixel rim the bilinear upsampling reads (18 x 18 flow pixels from a 20 x 20 tile of h: 1.23 x the
+// 1x1 stage, 1.27 x the 3x3 stage of a kernel that is bound by its launch, not by its arithmetic), kept in LDS after the
+// rounding of the store, and the tile's 32 x 32 upsampled pixels are written from there with bilerp_flow() -- the same
+// chain of fused multiply-adds on the same stored values as upsample2x_flow_pair_kernel: bit-identical to the two launches.
+// A rim pixel inside the image is computed by this tile and by its neighbour from the same operands in the same order;
+// one outside the image is never read (edge clamp).  Channels-last only.
+constexpr int kFuF = kFhTile + 2;      // 18: flow region
+constexpr int kFuH = kFhTile + 4;      // 20: h region
+template <typename T>
+__global__ __launch_bounds__(256, 2) void flow_head_up_kernel(const T* __restrict__ z, const float* __restrict__ params,
+                                                              T* __restrict__ out, T* __restrict__ out_up, int H, int W,
+                                                              int tiles_x, int tiles_y, float scale, float up_scale) {
+    QPWC_FLOW_CHAIN_PRIO();
+    constexpr int NH = kFuH * kFuH;                                    // 400 = 25 groups of 16 pixels
+    constexpr int NF = kFuF * kFuF;                                    // 324 flow pixels
+    __shared__ __attribute__((aligned(16))) float hs[NH * kFhC];
+    __shared__ __attribute__((aligned(8))) float2 fl[NF];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int x0 = tx * kFhTile, y0 = ty * kFhTile;
+    const float* w1 = params;
+    const float* b1 = params + 256;
+    const float* bs = params + 272;
+    const float* bt = params + 288;
+    const float* wf = params + 304;
+    const T* zb = z + (int64_t)b * H * W * kFhC;
+
+    // ---- h on the 20 x 20 region (flow_head_kernel's arithmetic) ----
+    const f32x4v w1v = *reinterpret_cast<const f32x4v*>(w1 + n * kFhC + 4 * g);
+    const float4 b1v = *reinterpret_cast<const float4*>(b1 + 4 * g);
+    const float4 bsv = *reinterpret_cast<const float4*>(bs + 4 * g);
+    const float4 btv = *reinterpret_cast<const float4*>(bt + 4 * g);
+    float4 wq[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        wq[k][0] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g);
+        wq[k][1] = *reinterpret_cast<const float4*>(wf + k * kFhC * 2 + 8 * g + 4);
+    }
+    constexpr int NG = NH / 16, NGW = (NG + 3) / 4;                    // 25 groups, at most 7 per wave
+    float4 av[NGW];
+    bool inb[NGW];
+#pragma unroll
+    for (int i = 0; i < NGW; ++i) {
+        const int grp = wave + 4 * i;
+        const int hp = 16 * grp + n;
+        const int ly = hp / kFuH, lx = hp - ly * kFuH;
+        const int gy = y0 - 2 + ly, gx = x0 - 2 + lx;
+        inb[i] = grp < NG && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inb[i]) av[i] = ld4(zb + ((int64_t)gy * W + gx) * kFhC + 4 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < NGW; ++i) {
+        const int grp = wave + 4 * i;
+        if (grp >= NG) break;   // wave-uniform
+        const int hp = 16 * grp + n;
+        float4 a = av[i];
+        if (inb[i]) a = make_float4(mishf(a.x), mishf(a.y), mishf(a.z), mishf(a.w));
+        f32x4v d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[0], a.x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[1], a.y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[2], a.z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[3], a.w, d, 0, 0, 0);
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inb[i])
+            h = make_float4(fmaf(mishf(d[0] + b1v.x), bsv.x, btv.x), fmaf(mishf(d[1] + b1v.y), bsv.y, btv.y),
+                            fmaf(mishf(d[2] + b1v.z), bsv.z, btv.z), fmaf(mishf(d[3] + b1v.w), bsv.w, btv.w));
+        *reinterpret_cast<float4*>(hs + hp * kFhC + 4 * g) = h;
+    }
+    __syncthreads();
+
+    // ---- 3x3 conv 16 -> 2 on the 18 x 18 flow region: groups of 16 flow pixels, lane = (pixel n of the group, quad g) ----
+    constexpr int NFG = (NF + 15) / 16;                                // 21 groups
+    for (int fg = wave; fg < NFG; fg += 4) {
+        const int fp_raw = 16 * fg + n;
+        const int fp = fp_raw < NF ? fp_raw : NF - 1;                  // (the last group's spare lanes repeat a pixel)
+        const int fyl = fp / kFuF, fxl = fp - fyl * kFuF;
+        float fx = 0.0f, fy = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 v = *reinterpret_cast<const float4*>(hs + ((fyl + ky) * kFuH + fxl + kx) * kFhC + 4 * g);
+                const float4 wa = wq[ky * 3 + kx][0], wb = wq[ky * 3 + kx][1];
+                fx = fmaf(v.x, wa.x, fx); fy = fmaf(v.x, wa.y, fy);
+                fx = fmaf(v.y, wa.z, fx); fy = fmaf(v.y, wa.w, fy);
+                fx = fmaf(v.z, wb.x, fx); fy = fmaf(v.z, wb.y, fy);
+                fx = fmaf(v.w, wb.z, fx); fy = fmaf(v.w, wb.w, fy);
+            }
+        fx += __shfl_xor(fx, 16); fy += __shfl_xor(fy, 16);
+        fx += __shfl_xor(fx, 32); fy += __shfl_xor(fy, 32);
+        if (g == 0 && fp_raw < NF) {
+            // the value as the level's flow tensor holds it (one rounding for fp16 storage): what the upsampling reads
+            T sx, sy;
+            st(&sx, scale * fx);
+            st(&sy, scale * fy);
+            fl[fp] = make_float2(ld(&sx), ld(&sy));
+            const int gx = x0 - 1 + fxl, gy = y0 - 1 + fyl;
+            if (fxl >= 1 && fxl <= kFhTile && fyl >= 1 && fyl <= kFhTile && gx < W && gy < H) {
+                T* o = out + ((int64_t)(b * H + gy) * W + gx) * 2;
+                o[0] = sx;
+                o[1] = sy;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the tile's 32 x 32 upsampled pixels, two horizontally adjacent ones per thread and trip ----
+    const int H2 = 2 * H, W2 = 2 * W;
+#pragma unroll
+    for (int r = 0; r < (2 * kFhTile * kFhTile) / 256; ++r) {
+        const int pi = tid + 256 * r;
+        const int yl = pi / kFhTile, j = pi - yl * kFhTile;
+        const int Y = 2 * y0 + yl, X = 2 * x0 + 2 * j;
+        if (Y >= H2 || X >= W2) continue;
+        const float sy = fmaxf(0.0f, (Y + 0.5f) * 0.5f - 0.5f);
+        const int yy0 = (int)sy;
+        const int yy1 = yy0 + 1 < H ? yy0 + 1 : H - 1;
+        const float ly = sy - yy0;
+        const int r0 = (yy0 - (y0 - 1)) * kFuF, r1 = (yy1 - (y0 - 1)) * kFuF;
+        float2 res[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int x = X + e;
+            const float sx = fmaxf(0.0f, (x + 0.5f) * 0.5f - 0.5f);
+            const int xx0 = (int)sx;
+            const int xx1 = xx0 + 1 < W ? xx0 + 1 : W - 1;
+            const float lx = sx - xx0;
+            const int c0 = xx0 - (x0 - 1), c1 = xx1 - (x0 - 1);
+            res[e] = bilerp_flow(ly, lx, fl[r0 + c0], fl[r0 + c1], fl[r1 + c0], fl[r1 + c1], up_scale);
+        }
+        T* o = out_up + ((int64_t)(b * H2 + Y) * W2 + X) * 2;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(res[0].x, res[0].y, res[1].x, res[1].y);
+        } else {
+            const __half2 a = __floats2half2_rn(res[0].x, res[0].y), c = __floats2half2_rn(res[1].x, res[1].y);
+            uint2 u;
+            u.x = *reinterpret_cast<const unsigned*>(&a);
+            u.y = *reinterpret_cast<const unsigned*>(&c);
+            *reinterpret_cast<uint2*>(o) = u;
+        }
+    }
+}
+
+int flow_head_up_launch(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
+                        float up_scale, int dtype, hipStream_t s) {
+    const int tiles_x = (W + kFhTile - 1) / kFhTile, tiles_y = (H + kFhTile - 1) / kFhTile;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * B));
+    if (dtype == QPWC_F32)
+        hipLaunchKernelGGL(flow_head_up_kernel<float>, grid, dim3(256), 0, s, (const float*)z, (const float*)params,
+                           (float*)out, (float*)out_up, H, W, tiles_x, tiles_y, scale, up_scale);
+    else
+        hipLaunchKernelGGL(flow_head_up_kernel<__half>, grid, dim3(256), 0, s, (const __half*)z, (const float*)params,
+                           (__half*)out, (__half*)out_up, H, W, tiles_x, tiles_y, scale, up_scale);
+    return check_launch("flow_head_up_kernel");
+}
+
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      int dtype, int out_layout, hipStream_t s) {
     const int out_nchw = out_layout == QPWC_NCHW;

@@ -442,6 +442,10 @@ class OptFlow(_Weighted):
     # (8 x 8 tiles with recomputed halos: 2.25 x the matrix work of the 64 -> 32 layer, irrelevant there).
     tail_max_pixels = 16384
 
+    fuse_upsample = False   # set by QpwcNet on its own blocks: flow head + the x2 upsampling of the flow in one launch
+    # ... where the two launches are bound by their start-up, not by their work (the fused one recomputes the tile's rim):
+    # config 2 (B=8: L3 65 k, L4 262 k pixels) 1.120 vs 1.124 ms/step with it, config 5 (B=32: L4 1 M pixels) 1.626 vs 1.617
+    fuse_upsample_max_pixels = 1 << 18
     def _pw_x3(self, i, first84=False):
         key = (i, bool(first84))
         t = self._pw_x3_cache.get(key)
@@ -571,7 +575,14 @@ class OptFlow(_Weighted):
                 z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1),
                                 self._pw_t84 if first84 else self._pw_t[i]).view(B, H, W, -1)
                 z_act = False
-        return ops.flow_head(z, self._head, scale, getattr(self, "out_format", CHANNELS_LAST))
+        out_format = getattr(self, "out_format", CHANNELS_LAST)
+        if self.fuse_upsample and out_format == CHANNELS_LAST and B * H * W <= self.fuse_upsample_max_pixels:
+            # round 4: the Upsample(2.0) that follows every level in QpwcNet's flow chain, by the flow head's own launch; the
+            # caller finds it on the returned flow (QpwcNet._up)
+            out, up = ops.flow_head_up(z, self._head, scale, 2.0)
+            out._qpwc_up2 = up
+            return out
+        return ops.flow_head(z, self._head, scale, out_format)
 
     def __call__(self, inputs):
         shape = parse_image_shape(inputs, self.data_format)

@@ -413,6 +413,28 @@ def flow_head(z, params, scale, out_format=CHANNELS_LAST):
     return out
 
 
+def flow_head_up(z, params, scale, up_scale=2.0):
+    """flow_head() (channels-last) and the Upsample(x2, * up_scale) that follows it in the flow chain (pwcnet.py:55,60) in one
+    launch (qpwc_flow_head_up_fwd) -> (flow (B,H,W,2), up_scale * bilinear x2 of it (B,2H,2W,2)); the second equals
+    upsample2x_flow(flow, up_scale) bit for bit."""
+    _check_tensor("z", z)
+    if z.shape[3] != 16 or not z.is_contiguous():
+        raise ValueError("z must be a dense (B,H,W,16) tensor")
+    L = _hip.lib()
+    if params.numel() != L.qpwc_flow_head_param_floats() or params.dtype != torch.float32 or \
+            not params.is_cuda or not params.is_contiguous():
+        raise ValueError("params must be a dense fp32 device vector of {} floats".format(
+            L.qpwc_flow_head_param_floats()))
+    B, H, W, _ = z.shape
+    out = torch.empty((B, H, W, 2), dtype=z.dtype, device=z.device)
+    up = torch.empty((B, 2 * H, 2 * W, 2), dtype=z.dtype, device=z.device)
+    with torch.cuda.device(z.device), _timed("flow_head", (B, H, W, 16)):
+        rc = L.qpwc_flow_head_up_fwd(z.data_ptr(), params.data_ptr(), out.data_ptr(), up.data_ptr(), B, H, W,
+                                     float(scale), float(up_scale), _DTYPES[z.dtype], _stream(z))
+    _hip.check(rc)
+    return out, up
+
+
 def optflow_tail(z2, dw3, pw3, b3, dw4, pw4, b4, head_params, scale, mish_on_load=False, out_format=CHANNELS_LAST):
     """Last two SeparableConv2D (64 -> 32 -> 16) + flow head of OptFlow (non_layers.py:223-231, 238-254,
     268-273) in one launch (qpwc_optflow_tail_fwd): z2 (B,H,W,64) fp32, the second layer's output (activated

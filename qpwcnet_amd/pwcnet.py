@@ -161,6 +161,19 @@ class QpwcNet:
         if self._df != self.data_format:
             for blk in [self.flow] + self.upflows:
                 blk.flow.out_format = self.data_format   # flow_head writes the (B,2,h,w) output itself
+        self.fuse_flow_upsample = True
+
+    @property
+    def fuse_flow_upsample(self):
+        """Flow head + the x2 upsampling of its flow in one launch (qpwc_flow_head_up_fwd) on the levels that run the
+        separate flow-head kernel (round 4)."""
+        return self._fuse_flow_upsample
+
+    @fuse_flow_upsample.setter
+    def fuse_flow_upsample(self, v):
+        self._fuse_flow_upsample = bool(v)
+        for blk in [self.flow] + self.upflows:
+            blk.flow.fuse_upsample = self._fuse_flow_upsample and self._df == self.data_format == CHANNELS_LAST
 
     @property
     def matmul(self):
@@ -182,6 +195,9 @@ class QpwcNet:
         """Upsample(scale=2.0) between levels (pwcnet.py:55,60).  A channels_first model on the
         channels-last kernels: the flow comes in the declared layout (flow_head wrote it so), the
         next level wants it channels-last, the last one is an output again."""
+        up = getattr(flo, "_qpwc_up2", None)
+        if up is not None and self._df == self.data_format == CHANNELS_LAST:
+            return up       # written by the flow head's own launch (OptFlow.fuse_upsample, qpwc_flow_head_up_fwd)
         if self._df != self.data_format and flo.is_cuda and flo.shape[1] == 2:
             return ops.upsample2x_flow(flo, 2.0, in_format=self.data_format,
                                        out_format=self.data_format if last else self._df)

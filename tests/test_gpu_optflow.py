@@ -69,6 +69,28 @@ def test_flow_head(hw):
     torch.testing.assert_close(out / scale, ref / scale, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("hw", [(16, 32), (33, 47), (5, 9), (128, 256), (1, 1), (17, 16)])
+def test_flow_head_up_is_flow_head_plus_upsample(hw, dtype):
+    """qpwc_flow_head_up_fwd (round 4): flow head and the x2 upsampling that follows it in ONE launch -- both outputs bit for
+    bit what the two launches write (tiles with the rim recomputed, ragged sizes, image edges, both storage types)."""
+    rng = np.random.default_rng(hw[0] * 131 + hw[1])
+    H, W = hw
+    B = 3
+    z = _rand(rng, B, H, W, 16).to(dtype).to(DEV)
+    w1, b1 = _rand(rng, 16, 16, 1, 1) * 0.3, _rand(rng, 16) * 0.1
+    gamma, beta = 1 + 0.1 * _rand(rng, 16), 0.1 * _rand(rng, 16)
+    mean, var = 0.1 * _rand(rng, 16), 1 + 0.2 * torch.rand(16)
+    wf = _rand(rng, 2, 16, 3, 3) * 0.2
+    scale = float(H * H + W * W) ** 0.5
+    params = non_layers.pack_flow_head(*(t.to(DEV) for t in (w1, b1, gamma, beta, mean, var)), 1e-3, wf.to(DEV))
+    flow = ops.flow_head(z, params, scale)
+    up = ops.upsample2x_flow(flow, 2.0)
+    flow1, up1 = ops.flow_head_up(z, params, scale, 2.0)
+    assert torch.equal(flow1, flow)
+    assert torch.equal(up1, up)
+
+
 def test_optflow_block_hip_equals_torch_path():
     """OptFlow.from_sources (HIP) == OptFlow(concat) (PyTorch convs) == oracle."""
     hw = (32, 64)
