@@ -1360,13 +1360,25 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const T* __rest
             if (gy < H && gx < W) v = ld<T>(xb + ((int64_t)c * H + gy) * W + gx);
             in_s[r * 6 + c] = v;
         }
-    } else
-    for (int idx = tid; idx < kFcIH * kFcIW * 3; idx += 256) {
-        const int row = idx / (kFcIW * 3), e = idx - row * (kFcIW * 3);   // e = float2 index inside the row
-        const int gy = 2 * Y0 + row, gx = 2 * X0 + e / 3;
-        float2 v = make_float2(0.f, 0.f);
-        if (gy < H && gx < W) v = ld2(xb + ((int64_t)gy * W + 2 * X0) * 6 + 2 * e);
-        *reinterpret_cast<float2*>(in_s + row * (kFcIW * 6) + 2 * e) = v;
+    } else {
+        // round 4: every request of the patch goes out before the first LDS write (as a rolled loop each of a thread's
+        // seven pieces was loaded, waited for with vmcnt(0) and written in turn: seven memory round trips per workgroup)
+        constexpr int NP = (kFcIH * kFcIW * 3 + 255) / 256;
+        float2 pv[NP];
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int idx = tid + 256 * it;
+            const int row = idx / (kFcIW * 3), e = idx - row * (kFcIW * 3);   // e = float2 index inside the row
+            const int gy = 2 * Y0 + row, gx = 2 * X0 + e / 3;
+            pv[it] = make_float2(0.f, 0.f);
+            if (idx < kFcIH * kFcIW * 3 && gy < H && gx < W) pv[it] = ld2(xb + ((int64_t)gy * W + 2 * X0) * 6 + 2 * e);
+        }
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int idx = tid + 256 * it;
+            const int row = idx / (kFcIW * 3), e = idx - row * (kFcIW * 3);
+            if (idx < kFcIH * kFcIW * 3) *reinterpret_cast<float2*>(in_s + row * (kFcIW * 6) + 2 * e) = pv[it];
+        }
     }
     float wv[9];
 #pragma unroll
@@ -1379,16 +1391,27 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const T* __rest
     f32x4e acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    // (round 4) a tap's four operand reads are issued together, one tap ahead of the matrix instructions that use them: as
+    // the compiler placed them every matrix instruction waited for its own ds_read_b32
+    float vb[2][4];
+    auto read_tap = [&](float (&v)[4], int k) __attribute__((always_inline)) {
+        const int ky = k / 3, kx = k - 3 * ky;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 4 * (wave & 1) + r;
+            v[r] = in_s[((2 * oy + ky) * kFcIW + 2 * n + kx) * 6 + 3 * f + (g < 3 ? g : 2)];   // (no branch around the read; k-slot 3 is zeroed at its use)
+        }
+    };
+    read_tap(vb[0], 0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+    for (int k = 0; k < 9; ++k) {
+        if (k + 1 < 9) read_tap(vb[(k + 1) & 1], k + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {   // 4 independent accumulators (output rows) per tap
-                const int oy = 4 * (wave & 1) + r;
-                const float v = g < 3 ? in_s[((2 * oy + ky) * kFcIW + 2 * n + kx) * 6 + 3 * f + g] : 0.0f;
-                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ky * 3 + kx], v, acc[r], 0, 0, 0);
-            }
+        for (int r = 0; r < 4; ++r)   // 4 independent accumulators (output rows) per tap
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[k], g < 3 ? vb[k & 1][r] : 0.0f, acc[r], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gy = Y0 + 4 * (wave & 1) + r, gx = X0 + n;
