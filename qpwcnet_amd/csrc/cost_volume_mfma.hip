@@ -1363,6 +1363,9 @@ static constexpr int lds_mode() { return 1; }
 
 // Region size policy of the workgroup-shared fp32 kernels (measured, tools/kbench.py --regions):
 // 16 x 16 regions need one workgroup of 16 waves per CU to be worth it.
+#ifndef QPWC_FUSED_MIN_REGIONS
+#define QPWC_FUSED_MIN_REGIONS 256   // 8 x 8 regions per launch from which the fused front end runs on the workgroup-shared kernel (fp32)
+#endif
 #ifndef QPWC_R16_MIN_WARP
 #define QPWC_R16_MIN_WARP 512    // 16 x 16 regions per launch from which the fused front end takes them (two rounds of
                                  // one-per-CU workgroups; see use_regions16)
@@ -1514,8 +1517,8 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, const void* flo, v
     if (pads_written) *pads_written = false;
     if (C % 16 != 0 || (reinterpret_cast<uintptr_t>(prv) | reinterpret_cast<uintptr_t>(nxt)) % 16)
         return 1;
-    if (flo && (C % 32 != 0 || reinterpret_cast<uintptr_t>(flo) % 8 || H < 2 || W < 2 ||
-                (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B < 256))
+    const int64_t regions8 = (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B;
+    if (flo && (C % 32 != 0 || reinterpret_cast<uintptr_t>(flo) % 8 || H < 2 || W < 2 || regions8 < QPWC_FUSED_MIN_REGIONS))
         return 1;
     if (flo && lds_mode() == 0) return 1;   // (experimental build, QPWC_CV_LDS=0: no fused form on the split-K kernel)
     // 32-bit byte offsets inside one image (buffer descriptors) and 32-bit element offsets
@@ -1527,7 +1530,7 @@ int cost_volume_mfma_launch(const void* prv, const void* nxt, const void* flo, v
     if (dtype == QPWC_F32) {
         // >= one region per CU: share the staged neighbourhood across a workgroup (L2 of the 256x512
         // pyramid, 256 regions x 4 steps: 10.2 us vs 11.8 us on the per-wave split-K kernel)
-        if (C % 32 == 0 && (int64_t)((W + 7) / 8) * ((H + 7) / 8) * B >= 256 && lds_mode() != 0)
+        if (C % 32 == 0 && regions8 >= (flo ? QPWC_FUSED_MIN_REGIONS : 256) && lds_mode() != 0)
         {
             // every tile dense: full 4x4 tiles, 16-byte aligned rows
             if (pads_written)
