@@ -57,3 +57,29 @@ def test_encoder_convolutions_are_run_to_run_stable(C):
     taps = ops.conv3x3_taps(_rnd(g, C, C, 3, 3) / (3 * C ** 0.5))
     bias = _rnd(g, C)
     _same_bits_every_launch(lambda: ops.conv3x3_mish(x, taps, bias))
+
+
+@pytest.mark.parametrize("shape", [(256, 8, 16, 128), (256, 16, 32, 64), (128, 32, 64, 32), (64, 64, 128, 16)],
+                         ids=["dec0", "dec1", "dec2", "dec3"])
+def test_decoder_upconv_with_skip_is_run_to_run_stable(shape):
+    """The decoder's transposed convolution + skip copy (qpwc_upconv4x4s2_mish_cat_fwd) at the step's four shapes."""
+    C, H, W, F = shape
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = _rnd(g, 16, H, W, C)
+    taps = ops.upconv_taps(_rnd(g, C, F, 4, 4) / (2 * C ** 0.5))
+    bias = _rnd(g, F)
+    skip = _rnd(g, 16, 2 * H, 2 * W, F)
+    dst = torch.empty(16, 2 * H, 2 * W, 2 * F, device=DEV)
+    _same_bits_every_launch(lambda: ops.upconv4x4s2_mish_cat_into(x, taps, bias, skip, dst))
+
+
+@pytest.mark.parametrize("hw", [(128, 256), (64, 128)], ids=["L4", "L3"])
+def test_flow_head_with_upsampling_is_run_to_run_stable(hw):
+    """qpwc_flow_head_up_fwd (its 1x1 stage runs on the fp32 matrix instructions) at the two levels that use it."""
+    from qpwcnet_amd import non_layers
+    g = torch.Generator(device=DEV).manual_seed(5)
+    z = _rnd(g, 8, hw[0], hw[1], 16)
+    params = non_layers.pack_flow_head(_rnd(g, 16, 16, 1, 1) * 0.3, _rnd(g, 16) * 0.1, 1 + 0.1 * _rnd(g, 16), 0.1 * _rnd(g, 16),
+                                       0.1 * _rnd(g, 16), 1 + 0.2 * torch.rand(16, device=DEV, generator=g), 1e-3,
+                                       _rnd(g, 2, 16, 3, 3) * 0.2)
+    _same_bits_every_launch(lambda: torch.cat([t.reshape(-1) for t in ops.flow_head_up(z, params, 100.0, 2.0)]))
