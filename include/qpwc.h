@@ -249,6 +249,14 @@ int qpwc_flow_head_param_floats(void);
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W,
                        float scale, int dtype, int out_layout, void* stream);
 
+/* Pointwise half of a SeparableConv2D whose depthwise half ran as qpwc_dwconv3x3_fwd (non_layers.py:223-231; the wide
+ * first OptFlow layer of the coarsest levels, which stay split): out (M, F) = y (M, C) . weight^T + bias, fp32, on the
+ * matrix cores, M = B*H*W pixels.  weight: (F, ceil(C/32)*32) row-major, zero padded (the layout qpwc_sepconv3x3_fwd
+ * takes); F in {16,32,64,128,256}.  Measured slower than hipBLASLt at the step's shapes: the network keeps the
+ * library GEMM for these two layers; this entry point serves callers that have none. */
+int qpwc_pointwise_bias_fwd(const void* y, const void* weight, const void* bias, void* out, int64_t M, int C, int F,
+                            void* stream);
+
 /* qpwc_flow_head_fwd (channels-last) AND the Upsample(scale = up_scale) that follows it in pwcnet.py:55,60 in one launch:
  * out (B,H,W,2) as there, out_up (B,2H,2W,2) = up_scale * UpSampling2D(2, 'bilinear')(out) -- bit for bit what
  * qpwc_upsample2x_flow_fwd returns for `out` (the tile's one-pixel rim is computed by the same workgroup). */

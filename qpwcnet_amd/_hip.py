@@ -25,7 +25,7 @@ SYMBOLS = (
     "qpwc_version", "qpwc_last_error", "qpwc_strerror", "qpwc_build_info", "qpwc_device_copy", "qpwc_clock_probe", "qpwc_layout_transpose_fwd", "qpwc_copy_pixels_fwd",
     "qpwc_cost_volume_fwd", "qpwc_cost_volume_fwd_strided", "qpwc_warp_fwd",
     "qpwc_warp_cost_volume_fwd", "qpwc_cost_volume_kernel", "qpwc_epe_workspace_floats", "qpwc_epe_fwd",
-    "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_flow_head_up_fwd", "qpwc_optflow_tail_fwd", "qpwc_bias_mish_fwd",
+    "qpwc_dwconv3x3_fwd", "qpwc_flow_head_param_floats", "qpwc_flow_head_fwd", "qpwc_flow_head_up_fwd", "qpwc_pointwise_bias_fwd", "qpwc_optflow_tail_fwd", "qpwc_bias_mish_fwd",
     "qpwc_upsample2x_flow_fwd", "qpwc_epe_multi_workspace_floats", "qpwc_epe_multi_fwd", "qpwc_epe_multi_mixed_fwd",
     "qpwc_cost_volume_to_flow_fwd", "qpwc_sepconv3x3_fwd", "qpwc_sepconv3x3_f16_fwd", "qpwc_bias_mish_pad_fwd", "qpwc_split_frames_pad_fwd",
     "qpwc_invert_flow_fwd", "qpwc_occlusion_fwd", "qpwc_conv3x3_mish_fwd", "qpwc_conv3x3_mish_f16_fwd", "qpwc_conv3x3_mish_x3_fwd", "qpwc_split_bf16x3_fwd", "qpwc_sepconv3x3_x3_fwd", "qpwc_conv3x3s2_mish_x3_fwd", "qpwc_upconv4x4s2_mish_x3_fwd",
@@ -103,6 +103,8 @@ def lib():
     L.qpwc_flow_head_fwd.restype = ci
     L.qpwc_flow_head_up_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, cf, cf, ci, vp]
     L.qpwc_flow_head_up_fwd.restype = ci
+    L.qpwc_pointwise_bias_fwd.argtypes = [vp, vp, vp, vp, i64, ci, ci, vp]
+    L.qpwc_pointwise_bias_fwd.restype = ci
     L.qpwc_optflow_tail_fwd.argtypes = [vp] * 9 + [ci, ci, ci, cf, ci, ci, vp]
     L.qpwc_optflow_tail_fwd.restype = ci
     L.qpwc_bias_mish_fwd.argtypes = [vp, vp, i64, ci, ci, vp]

@@ -61,6 +61,8 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
 int flow_head_launch(const void* z, const void* params, void* out, int B, int H, int W, float scale,
                      int dtype, int out_layout, hipStream_t s);
 int flow_head_param_floats();
+int pointwise_bias_launch(const void* y, const void* w, const void* bias, void* out, int64_t M, int C, int cpad, int F,
+                          hipStream_t s);
 int flow_head_up_launch(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
                         float up_scale, int dtype, hipStream_t s);
 int optflow_tail_launch(const void* z2, const void* dw3, const void* pw3, const void* b3, const void* dw4,
@@ -455,6 +457,19 @@ int qpwc_sepconv3x3_f16_fwd(const void* const* src, const int* src_channels, con
     if (mish_flags < 0 || mish_flags > 3) return fail(QPWC_E_SHAPE, "mish_flags %d outside [0,3]", mish_flags);
     return sepconv3x3_f16_launch(src, src_channels, src_pixel_stride, n_src, mish_flags, dw, pw, bias, out, B,
                                  H, W, F, (hipStream_t)stream);
+}
+
+int qpwc_pointwise_bias_fwd(const void* y, const void* weight, const void* bias, void* out, int64_t M, int C, int F,
+                            void* stream) {
+    if (!y || !weight || !bias || !out) return fail(QPWC_E_NULL, "null pointer argument");
+    if (M <= 0 || C <= 0) return fail(QPWC_E_SHAPE, "non-positive extent M=%lld C=%d", (long long)M, C);
+    if (F != 16 && F != 32 && F != 64 && F != 128 && F != 256) return fail(QPWC_E_SHAPE, "F=%d not in {16,32,64,128,256}", F);
+    if (M * (int64_t)(C > F ? C : F) >= INT32_MAX) return fail(QPWC_E_SHAPE, "M x max(C, F) must stay below 2^31");
+    if ((uintptr_t)y % 16 || (uintptr_t)weight % 16 || (uintptr_t)bias % 16 || (uintptr_t)out % 16)
+        return fail(QPWC_E_ALIGN, "y, weight, bias, out must be 16-byte aligned");
+    const int cpad = (C + 31) / 32 * 32;
+    if (overlaps(out, (size_t)M * F * 4, y, (size_t)M * C * 4)) return fail(QPWC_E_ALIAS, "out overlaps y");
+    return pointwise_bias_launch(y, weight, bias, out, M, C, cpad, F, (hipStream_t)stream);
 }
 
 int qpwc_flow_head_param_floats(void) { return flow_head_param_floats(); }

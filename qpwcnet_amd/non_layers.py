@@ -442,6 +442,11 @@ class OptFlow(_Weighted):
     # (8 x 8 tiles with recomputed halos: 2.25 x the matrix work of the 64 -> 32 layer, irrelevant there).
     tail_max_pixels = 16384
 
+    # the split layers' pointwise half by qpwc_pointwise_bias_fwd instead of the library GEMM: built, parity-green, SLOWER -- 15.4 /
+    # 12.3 / 23.1 us against 7.5 / 10.6 / 13.1 us for hipBLASLt at the L0 / L1 / L2 shapes (tools/pwbench.py), step 1.131 vs 1.116 ms:
+    # with 16 pixels per workgroup every workgroup streams the whole (F, C) weight matrix from L2.  Off; the two library
+    # GEMMs of L0 / L1 stay the only library launches of a step.
+    own_pointwise = False
     fuse_upsample = False   # set by QpwcNet on its own blocks: flow head + the x2 upsampling of the flow in one launch
     # ... where the two launches are bound by their start-up, not by their work (the fused one recomputes the tile's rim):
     # config 2 (B=8: L3 65 k, L4 262 k pixels) 1.120 vs 1.124 ms/step with it, config 5 (B=32: L4 1 M pixels) 1.626 vs 1.617
@@ -572,8 +577,15 @@ class OptFlow(_Weighted):
                 z_act = act_out
             else:
                 y = ops.dwconv3x3(src, dw_i, mish_on_load=act_in)
-                z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1),
-                                self._pw_t84 if first84 else self._pw_t[i]).view(B, H, W, -1)
+                pw_i = self._pw_pad84 if first84 else self._pw_pad[i]
+                if self.own_pointwise and fp32 and pw_i.shape[0] in (16, 32, 64, 128, 256) and \
+                        pw_i.shape[1] == (y.shape[3] + 31) // 32 * 32:
+                    # round 4: the pointwise half on the own matrix-core kernel (the library GEMM was the last library
+                    # launch of a step: 12-14 us for a start-up bound 1 k / 4 k-row product)
+                    z = ops.pointwise_bias(y, pw_i, self._pw_b32[i])
+                else:
+                    z = torch.addmm(self._pw_b[i], y.view(B * H * W, -1),
+                                    self._pw_t84 if first84 else self._pw_t[i]).view(B, H, W, -1)
                 z_act = False
         out_format = getattr(self, "out_format", CHANNELS_LAST)
         if self.fuse_upsample and out_format == CHANNELS_LAST and B * H * W <= self.fuse_upsample_max_pixels:

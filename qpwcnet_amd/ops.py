@@ -413,6 +413,26 @@ def flow_head(z, params, scale, out_format=CHANNELS_LAST):
     return out
 
 
+def pointwise_bias(y, pw_padded, bias):
+    """Pointwise 1x1 + bias of a split SeparableConv2D on the matrix cores (qpwc_pointwise_bias_fwd): y (..., C) fp32 dense
+    -> (..., F) = y . W^T + bias, W = pw_padded (F, ceil(C/32)*32) from pad_pointwise().  The own replacement of the library
+    GEMM behind dwconv3x3() on the few-pixel levels."""
+    if not isinstance(y, torch.Tensor) or not y.is_cuda:
+        raise RuntimeError("qpwcnet_amd: y must be a tensor on a HIP device (no CPU fallback)")
+    C = y.shape[-1]
+    F_, cpad = pw_padded.shape
+    if y.dtype != torch.float32 or not y.is_contiguous() or pw_padded.dtype != torch.float32 or not pw_padded.is_contiguous() \
+            or cpad != (C + 31) // 32 * 32 or bias.numel() != F_ or bias.dtype != torch.float32 or not bias.is_contiguous():
+        raise ValueError("pointwise_bias takes dense fp32 y (..., C), weights (F, ceil(C/32)*32) from pad_pointwise, bias (F)")
+    M = y.numel() // C
+    out = torch.empty(y.shape[:-1] + (F_,), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device), _timed("pointwise_bias", (M, C, F_)):
+        rc = _hip.lib().qpwc_pointwise_bias_fwd(y.data_ptr(), pw_padded.data_ptr(), bias.data_ptr(), out.data_ptr(), M, C, F_,
+                                                _stream(y))
+    _hip.check(rc)
+    return out
+
+
 def flow_head_up(z, params, scale, up_scale=2.0):
     """flow_head() (channels-last) and the Upsample(x2, * up_scale) that follows it in the flow chain (pwcnet.py:55,60) in one
     launch (qpwc_flow_head_up_fwd) -> (flow (B,H,W,2), up_scale * bilinear x2 of it (B,2H,2W,2)); the second equals

@@ -91,6 +91,27 @@ def test_flow_head_up_is_flow_head_plus_upsample(hw, dtype):
     assert torch.equal(up1, up)
 
 
+@pytest.mark.parametrize("M,C,F", [(1024, 596, 128), (4096, 342, 128), (16384, 211, 128), (1000, 37, 16), (17, 64, 32),
+                                   (5, 596, 256), (4096, 128, 64)])
+def test_pointwise_bias_against_float64(M, C, F):
+    """qpwc_pointwise_bias_fwd (round 4): the pointwise half of a split SeparableConv2D, y . W^T + b on the fp32 matrix
+    instructions, against float64 -- the step's two shapes (L0 / L1 first layers), odd channel counts (rows that straddle
+    the 16-byte loads), a last tile with fewer than 16 rows, every output width; and run-to-run bit stability."""
+    rng = np.random.default_rng(M + C + F)
+    y = _rand(rng, M, C).to(DEV)
+    w = (_rand(rng, F, C) / np.sqrt(C)).to(DEV)
+    b = _rand(rng, F).to(DEV)
+    out = ops.pointwise_bias(y, ops.pad_pointwise(w), b)
+    ref = (y.double() @ w.double().t() + b.double())
+    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+    lib = torch.addmm(b, y, w.t())
+    torch.testing.assert_close(out, lib, rtol=0, atol=2e-5)
+    for _ in range(5):
+        assert torch.equal(ops.pointwise_bias(y, ops.pad_pointwise(w), b), out)
+    with pytest.raises(ValueError):
+        ops.pointwise_bias(y, ops.pad_pointwise(w)[:, :-32].contiguous() if C > 32 else w, b)
+
+
 def test_optflow_block_hip_equals_torch_path():
     """OptFlow.from_sources (HIP) == OptFlow(concat) (PyTorch convs) == oracle."""
     hw = (32, 64)
