@@ -272,3 +272,36 @@ def test_full_network_dispatch_rules_at_other_sizes(hw, batch):
         assert a.shape[0] == batch
         e = float(torch_ref.epe_error(a[sub].cpu(), b))
         assert e < TOL, "level {} EPE vs oracle {:.3e}".format(lvl, e)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_round4_launch_folding_switches_do_not_change_a_bit(dtype):
+    """The launches folded into their neighbours in round 4 (the decoder's skip copies into the transposed convolution,
+    the x2 upsampling of the flow into the flow head) and the two switched-off orderings of the skip copies
+    (prefill_skips, skip_copy_first) only move work between launches: every variant returns the default forward's flows
+    bit for bit (B = 8, 256 x 512, eager two-stream forward)."""
+    hw, B = (256, 512), 8
+    weights = synth.make_weights(42, hw)
+    pairs, _ = synth.make_frames(B, hw[0], hw[1], seed=21)
+    x = torch.from_numpy(pairs).to(DEV, dtype)
+
+    def run(**attrs):
+        model = build_flower(True, hw, "channels_last", weights=weights, device=DEV, dtype=dtype)
+        for k, v in attrs.items():
+            if k == "fuse_skip_copy":
+                for d in model.dec:
+                    d.fuse_skip_copy = v
+            else:
+                setattr(model, k, v)
+        with torch.no_grad():
+            flows = model(x)
+        torch.cuda.synchronize()
+        return [f.clone() for f in flows]
+
+    ref = run()
+    for attrs in ({"fuse_skip_copy": False}, {"fuse_flow_upsample": False}, {"prefill_skips": True},
+                  {"skip_copy_first": (3, 2)}, {"fuse_skip_copy": False, "prefill_skips": True}):
+        got = run(**attrs)
+        for lvl, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), "{}: level {} differs (max |diff| {:.3g})".format(
+                attrs, lvl, float((a.float() - b.float()).abs().max()))
