@@ -104,6 +104,14 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 // it waited with vmcnt(7), (6), .. (0) through the trip's eight groups of matrix instructions -- i.e. for the requests that
 // were issued a moment ago at the top of THIS trip, one by one, instead of for the ones issued a whole trip earlier
 // (vmcnt is a counter of outstanding requests, in order): an L2 round trip exposed at the top of every 32-channel block.
+#ifndef QPWC_UPCONV_LDS_TOTAL
+#define QPWC_UPCONV_LDS_TOTAL 0
+#endif
+#ifndef QPWC_UPCONV64_LDS_TOTAL
+#define QPWC_UPCONV64_LDS_TOTAL 82944   // the same for the finest decoder level only (it has ~120 us of slack before flow level 4
+                                        // needs it): ONE of its workgroups per CU leaves the flow chain's 79-80 KiB workgroups room beside
+                                        // it -- config 2 step 1.1124 vs 1.1158 ms (five interleaved pairs); 0 = off
+#endif
 #ifndef QPWC_W_NEXT_ALWAYS
 #define QPWC_W_NEXT_ALWAYS 1
 #endif
@@ -1134,7 +1142,14 @@ static int upconv_launch_t(const void* x, const void* weight, const void* bias, 
         set_error("upconv4x4s2_mish: too many tiles");
         return QPWC_E_SHAPE;
     }
-    hipLaunchKernelGGL((upconv4x4s2_mish_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), 0, s,
+    // QPWC_UPCONV_LDS_TOTAL (A/B, round 4): pad the workgroup's LDS footprint to this many bytes with dynamic LDS the kernel never
+    // touches -- 81 KiB leaves ONE decoder workgroup per CU and room for a 79 KiB SeparableConv2D workgroup of the flow chain
+    constexpr size_t kStatic = (size_t)(TH + 2) * kEcHW * C * sizeof(float);
+    // (the finest decoder level of a SMALL step only: at config 4's 32 k workgroups one per CU costs +0.7 %)
+    const size_t want = (C == 64 && QPWC_UPCONV64_LDS_TOTAL && n_tiles * (F / 16) <= 2048) ? QPWC_UPCONV64_LDS_TOTAL
+                                                                                         : QPWC_UPCONV_LDS_TOTAL;
+    const size_t extra = want > kStatic ? want - kStatic : 0;
+    hipLaunchKernelGGL((upconv4x4s2_mish_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), extra, s,
                        (const float*)x, (const float*)weight, (const float*)bias, (float*)out, H, W, F,
                        out_pixel_stride, tiles_x, tiles_y, (int)n_tiles, skip);
     return check_launch("upconv4x4s2_mish_kernel");

@@ -131,6 +131,7 @@ class QpwcNet:
         self.dec_chunk_max_pixels = 64 * 256 * 512
         # launch order of flow levels (F) and decoder levels (D) in the two-stream forward, see _forward_two_streams
         self.capture_order = ("F0", "D0", "D1", "D2", "D3", "F1", "F2", "F3", "F4")
+        self.dec_after_flow = {}     # {decoder level: flow level it waits for}; see _forward_two_streams
         self._matmul = "f32"
         self.skip_redundant_join = True   # see the end of _forward_two_streams
         self.input_shape = tuple(input_shape)
@@ -366,7 +367,7 @@ class QpwcNet:
                 buf = self.dec[i].prefill_skip(encs[-2 - i], c_in)
             if buf is not None:
                 self._prefilled[i] = buf
-        ready, decs, flos, ran_on = {}, {}, [], {}
+        ready, decs, flos, ran_on, flow_done = {}, {}, [], {}, {}
         waited_on_main = set()      # decoder levels whose `ready` event the caller's stream has waited for
         f, k, flo = encs[-1], -2, None
         for tok in order:
@@ -377,6 +378,13 @@ class QpwcNet:
                 side = main if tok[0] == "M" else sides[self.dec_stream_of[i]]
                 if i > 0 and ran_on[i - 1] is not side:
                     side.wait_event(ready[i - 1])       # the previous decoder level ran on another stream
+                # dec_after_flow (A/B, round 4): decoder level i is held back until flow level j has finished (j must come
+                # before D<i> in capture_order) -- to choose WHICH flow-chain kernels the level's launches share the chip with
+                j_hold = self.dec_after_flow.get(i)
+                if j_hold is not None and side is not main:
+                    if j_hold not in flow_done:
+                        raise ValueError("dec_after_flow: F{} must precede D{} in capture_order".format(j_hold, i))
+                    side.wait_event(flow_done[j_hold])
                 with torch.cuda.stream(side):
                     hip_chunks = (self.dec_chunks[i] if small else 1) if tok[0] == "D" else 1
                     f = self.dec[i].cat_skip(f, encs[k], batch_chunks=chunks if tok[0] == "D" else 1, hip_chunks=hip_chunks,
@@ -402,6 +410,9 @@ class QpwcNet:
                     waited_on_main.add(i - 1)
                 flo = self.upflows[i - 1]((decs[i - 1][:nb], decs[i - 1][nb:], flo_u))
                 flos.append(flo)
+            if tok[0] == "F" and i in self.dec_after_flow.values():
+                flow_done[i] = torch.cuda.Event()
+                flow_done[i].record(main)
         flos.append(self._up(flo, last=True))
         # Join before anything is freed or returned.  A side stream whose LAST operation main has already waited for
         # (ready[i] of the last decoder level it ran, consumed by flow level i + 1) is joined already: another wait on
