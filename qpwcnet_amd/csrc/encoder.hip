@@ -104,6 +104,12 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 // it waited with vmcnt(7), (6), .. (0) through the trip's eight groups of matrix instructions -- i.e. for the requests that
 // were issued a moment ago at the top of THIS trip, one by one, instead of for the ones issued a whole trip earlier
 // (vmcnt is a counter of outstanding requests, in order): an L2 round trip exposed at the top of every 32-channel block.
+#ifndef QPWC_UPCONV256_TH
+#define QPWC_UPCONV256_TH 2   // input rows per workgroup of the 256- / 128-channel transposed convolutions (A/B, round 4)
+#endif
+#ifndef QPWC_UPCONV128_TH
+#define QPWC_UPCONV128_TH 4
+#endif
 #ifndef QPWC_UPCONV_LDS_TOTAL
 #define QPWC_UPCONV_LDS_TOTAL 0
 #endif
@@ -1161,8 +1167,8 @@ int upconv4x4s2_mish_launch(const void* x, const void* weight, const void* bias,
     const UpSkip sk{skip, (long long)skip_bs, (long long)skip_rs, (long long)skip_ps};
     switch (C) {
         case 64: return upconv_launch_t<64, 8>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
-        case 128: return upconv_launch_t<128, 4>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
-        case 256: return upconv_launch_t<256, 2>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
+        case 128: return upconv_launch_t<128, QPWC_UPCONV128_TH>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
+        case 256: return upconv_launch_t<256, QPWC_UPCONV256_TH>(x, weight, bias, out, B, H, W, F, out_pixel_stride, s, sk);
         default: set_error("upconv4x4s2_mish: C=%d not in {64,128,256}", C); return QPWC_E_SHAPE;
     }
 }
