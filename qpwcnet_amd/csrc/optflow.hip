@@ -812,6 +812,9 @@ __global__ __launch_bounds__(256, 2) void sepconv3x3_fused_kernel(
 #include "experimental/sepconv_flat.inc"
 #endif
 
+#ifndef QPWC_SC_SPLIT_ONE_ROUND
+#define QPWC_SC_SPLIT_ONE_ROUND 0   // 0 = off; else the smallest F it applies to
+#endif
 #ifndef QPWC_SC_SLICE_TARGET
 #define QPWC_SC_SLICE_TARGET 192   // split a layer's outputs over workgroups until the launch has this many
 #endif
@@ -873,6 +876,9 @@ int sepconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* 
     // outputs) until the launch has ~one workgroup per CU
     int slices = 1;
     while (nblk * slices < QPWC_SC_SLICE_TARGET && F / (slices * 2) >= 16) slices *= 2;
+    // A/B (round 4): a launch of 257..512 tiles is ONE round of two workgroups per CU -- every workgroup's prologue and
+    // epilogue exposed at the same time; with its outputs split over two workgroups per tile it is two rounds
+    if (QPWC_SC_SPLIT_ONE_ROUND && slices == 1 && nblk > 256 && nblk <= 512 && F >= QPWC_SC_SPLIT_ONE_ROUND) slices = 2;
     const dim3 grid((unsigned)(nblk * slices));
     // 16-byte loads: every source but the last holds a multiple of 4 channels in 16-byte aligned
     // pixels; the last one either does too or is read element-wise (it must not straddle a quad
