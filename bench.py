@@ -734,6 +734,8 @@ def compact_line(full):
         line["per_level_epe_vs_oracle"] = _r(full["per_level_epe_vs_oracle"], 3)
     if "parity_gate" in full:
         line["parity_gate"] = {"tol": full["parity_gate"]["tolerance_px"], "pass": full["parity_gate"]["pass"]}
+        if "skipped" in full["parity_gate"]:
+            line["parity_gate"]["skipped"] = full["parity_gate"]["skipped"]
     if "serving_throughput" in full:
         st = full["serving_throughput"]
         line["serving_throughput"] = {"value": _r(st["value"]), "batches_in_flight": st["batches_in_flight"]}
@@ -887,6 +889,10 @@ def main():
             print("bench.py: PARITY FAILURE: per-level EPE vs the oracle {} >= {} px".format(
                 result["per_level_epe_vs_oracle"], PARITY_TOL_PX), file=sys.stderr)
             rc = 3
+    elif rank == 0:
+        # said, not silent: this run did not compare its flows with the oracle (--no-cpu-baseline, N > 1 ranks, fp16 or bf16x3)
+        result["parity_gate"] = {"tolerance_px": PARITY_TOL_PX, "pass": None,
+                                 "skipped": "no oracle comparison in this run (the default N=1 fp32 run makes it)"}
     if rank == 0:
         result["detail_file"] = None
         if args.detail:
