@@ -259,9 +259,11 @@ int qpwc_pointwise_bias_fwd(const void* y, const void* weight, const void* bias,
 
 /* qpwc_flow_head_fwd (channels-last) AND the Upsample(scale = up_scale) that follows it in pwcnet.py:55,60 in one launch:
  * out (B,H,W,2) as there, out_up (B,2H,2W,2) = up_scale * UpSampling2D(2, 'bilinear')(out) -- bit for bit what
- * qpwc_upsample2x_flow_fwd returns for `out` (the tile's one-pixel rim is computed by the same workgroup). */
-int qpwc_flow_head_up_fwd(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
-                          float up_scale, int dtype, void* stream);
+ * qpwc_upsample2x_flow_fwd returns for `out` (the tile's one-pixel rim is computed by the same workgroup).
+ * out_up_f32 (fp16 storage only, else NULL): the values of out_up once more as fp32 (B,2H,2W,2) -- the coordinates the next
+ * level's WarpV2 takes, which would otherwise be a cast launch of their own. */
+int qpwc_flow_head_up_fwd(const void* z, const void* params, void* out, void* out_up, void* out_up_f32, int B, int H, int W,
+                          float scale, float up_scale, int dtype, void* stream);
 
 /* The tail of OptFlow.__call__ in one launch, for small images (coarse pyramid levels), fp32 channels-last:
  *   z3   = Mish(SeparableConv2D_3(z2))    64 -> 32   (non_layers.py:223-231, third of the four)

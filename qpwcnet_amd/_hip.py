@@ -101,7 +101,7 @@ def lib():
     L.qpwc_flow_head_param_floats.restype = ci
     L.qpwc_flow_head_fwd.argtypes = [vp, vp, vp, ci, ci, ci, cf, ci, ci, vp]
     L.qpwc_flow_head_fwd.restype = ci
-    L.qpwc_flow_head_up_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, cf, cf, ci, vp]
+    L.qpwc_flow_head_up_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, ci, vp]
     L.qpwc_flow_head_up_fwd.restype = ci
     L.qpwc_pointwise_bias_fwd.argtypes = [vp, vp, vp, vp, i64, ci, ci, vp]
     L.qpwc_pointwise_bias_fwd.restype = ci

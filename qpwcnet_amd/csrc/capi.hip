@@ -63,8 +63,8 @@ int flow_head_launch(const void* z, const void* params, void* out, int B, int H,
 int flow_head_param_floats();
 int pointwise_bias_launch(const void* y, const void* w, const void* bias, void* out, int64_t M, int C, int cpad, int F,
                           hipStream_t s);
-int flow_head_up_launch(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
-                        float up_scale, int dtype, hipStream_t s);
+int flow_head_up_launch(const void* z, const void* params, void* out, void* out_up, void* out_up_f32, int B, int H, int W,
+                        float scale, float up_scale, int dtype, hipStream_t s);
 int optflow_tail_launch(const void* z2, const void* dw3, const void* pw3, const void* b3, const void* dw4,
                         const void* pw4, const void* b4, const void* head, void* out, int B, int H, int W,
                         float scale, int act_in, int out_layout, hipStream_t s);
@@ -474,8 +474,8 @@ int qpwc_pointwise_bias_fwd(const void* y, const void* weight, const void* bias,
 
 int qpwc_flow_head_param_floats(void) { return flow_head_param_floats(); }
 
-int qpwc_flow_head_up_fwd(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
-                          float up_scale, int dtype, void* stream) {
+int qpwc_flow_head_up_fwd(const void* z, const void* params, void* out, void* out_up, void* out_up_f32, int B, int H, int W,
+                          float scale, float up_scale, int dtype, void* stream) {
     if (!z || !params || !out || !out_up) return fail(QPWC_E_NULL, "null pointer argument");
     if (dtype != QPWC_F32 && dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "unsupported dtype %d", dtype);
     const size_t es = esize(dtype);
@@ -486,7 +486,14 @@ int qpwc_flow_head_up_fwd(const void* z, const void* params, void* out, void* ou
     const size_t nz = (size_t)B * H * W * 16 * es, no = (size_t)B * H * W * 2 * es, nu = 4 * no;
     if (overlaps(out, no, z, nz) || overlaps(out_up, nu, z, nz) || overlaps(out_up, nu, out, no))
         return fail(QPWC_E_ALIAS, "out / out_up overlap z or each other");
-    return flow_head_up_launch(z, params, out, out_up, B, H, W, scale, up_scale, dtype, (hipStream_t)stream);
+    if (out_up_f32) {
+        if (dtype != QPWC_F16) return fail(QPWC_E_DTYPE, "out_up_f32 is the fp32 copy of an fp16 out_up: pass NULL for fp32 storage");
+        if ((uintptr_t)out_up_f32 % 16) return fail(QPWC_E_ALIGN, "out_up_f32 must be 16-byte aligned");
+        if (overlaps(out_up_f32, (size_t)B * 4 * H * W * 2 * 4, z, nz) || overlaps(out_up_f32, (size_t)B * 4 * H * W * 2 * 4, out, no) ||
+            overlaps(out_up_f32, (size_t)B * 4 * H * W * 2 * 4, out_up, nu))
+            return fail(QPWC_E_ALIAS, "out_up_f32 overlaps another operand");
+    }
+    return flow_head_up_launch(z, params, out, out_up, out_up_f32, B, H, W, scale, up_scale, dtype, (hipStream_t)stream);
 }
 
 int qpwc_flow_head_fwd(const void* z, const void* params, void* out, int B, int H, int W, float scale,

@@ -1657,7 +1657,8 @@ constexpr int kFuF = kFhTile + 2;      // 18: flow region
 constexpr int kFuH = kFhTile + 4;      // 20: h region
 template <typename T>
 __global__ __launch_bounds__(256, 2) void flow_head_up_kernel(const T* __restrict__ z, const float* __restrict__ params,
-                                                              T* __restrict__ out, T* __restrict__ out_up, int H, int W,
+                                                              T* __restrict__ out, T* __restrict__ out_up,
+                                                              float* __restrict__ out_up_f32, int H, int W,
                                                               int tiles_x, int tiles_y, float scale, float up_scale) {
     QPWC_FLOW_CHAIN_PRIO();
     constexpr int NH = kFuH * kFuH;                                    // 400 = 25 groups of 16 pixels
@@ -1790,20 +1791,26 @@ __global__ __launch_bounds__(256, 2) void flow_head_up_kernel(const T* __restric
             u.x = *reinterpret_cast<const unsigned*>(&a);
             u.y = *reinterpret_cast<const unsigned*>(&c);
             *reinterpret_cast<uint2*>(o) = u;
+            // the SAME values as fp32 (what `out_up.float()` holds): the next level's warp takes fp32 coordinates whatever
+            // the storage type, and that cast was a launch of its own per level (4.7 us each, config 5)
+            if (out_up_f32 != nullptr) {
+                const float2 fa = __half22float2(a), fc = __half22float2(c);
+                *reinterpret_cast<float4*>(out_up_f32 + ((int64_t)(b * H2 + Y) * W2 + X) * 2) = make_float4(fa.x, fa.y, fc.x, fc.y);
+            }
         }
     }
 }
 
-int flow_head_up_launch(const void* z, const void* params, void* out, void* out_up, int B, int H, int W, float scale,
-                        float up_scale, int dtype, hipStream_t s) {
+int flow_head_up_launch(const void* z, const void* params, void* out, void* out_up, void* out_up_f32, int B, int H, int W,
+                        float scale, float up_scale, int dtype, hipStream_t s) {
     const int tiles_x = (W + kFhTile - 1) / kFhTile, tiles_y = (H + kFhTile - 1) / kFhTile;
     const dim3 grid((unsigned)(tiles_x * tiles_y * B));
     if (dtype == QPWC_F32)
         hipLaunchKernelGGL(flow_head_up_kernel<float>, grid, dim3(256), 0, s, (const float*)z, (const float*)params,
-                           (float*)out, (float*)out_up, H, W, tiles_x, tiles_y, scale, up_scale);
+                           (float*)out, (float*)out_up, (float*)nullptr, H, W, tiles_x, tiles_y, scale, up_scale);
     else
         hipLaunchKernelGGL(flow_head_up_kernel<__half>, grid, dim3(256), 0, s, (const __half*)z, (const float*)params,
-                           (__half*)out, (__half*)out_up, H, W, tiles_x, tiles_y, scale, up_scale);
+                           (__half*)out, (__half*)out_up, (float*)out_up_f32, H, W, tiles_x, tiles_y, scale, up_scale);
     return check_launch("flow_head_up_kernel");
 }
 

@@ -721,7 +721,10 @@ class UpFlow(_Weighted):
         prv, nxt, flo = inputs
         r = self.cost_volume.search_range
         if self.fuses(prv, flo):
-            flo32 = flo.to(torch.float32).contiguous()   # coordinates are fp32 whatever the storage dtype
+            # coordinates are fp32 whatever the storage dtype (fp16 storage: flow_head_up() wrote them beside the flow)
+            flo32 = getattr(flo, "_qpwc_f32", None) if flo.dtype == torch.float16 else None
+            if flo32 is None:
+                flo32 = flo.to(torch.float32).contiguous()
             if self.flow.wants_cost84(prv):
                 cost = _cost84(prv, nxt, r, flo=flo32)
             else:

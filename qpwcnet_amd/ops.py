@@ -267,7 +267,9 @@ def _flow_physical(flo, dims, data_format, layout):
             raise ValueError("flo shape {} is not broadcastable to the image".format(
                 tuple(flo.shape)))
         mask |= bit
-    f = flo.to(torch.float32)
+    f = getattr(flo, "_qpwc_f32", None) if flo.dtype == torch.float16 else None   # written beside it by flow_head_up()
+    if f is None:
+        f = flo.to(torch.float32)
     if data_format == CHANNELS_FIRST and layout == _hip.NHWC:
         f = f.permute(0, 2, 3, 1)  # image is physically NHWC: give the flow the same layout
     return f.contiguous(), mask
@@ -448,10 +450,16 @@ def flow_head_up(z, params, scale, up_scale=2.0):
     B, H, W, _ = z.shape
     out = torch.empty((B, H, W, 2), dtype=z.dtype, device=z.device)
     up = torch.empty((B, 2 * H, 2 * W, 2), dtype=z.dtype, device=z.device)
+    # fp16 storage: the upsampled flow once more as fp32, written by the same launch (== up.float(); found by its consumers
+    # as up._qpwc_f32: the next level's WarpV2 takes fp32 coordinates, and the cast was a launch of its own per level)
+    up32 = torch.empty((B, 2 * H, 2 * W, 2), dtype=torch.float32, device=z.device) if z.dtype == torch.float16 else None
     with torch.cuda.device(z.device), _timed("flow_head", (B, H, W, 16)):
-        rc = L.qpwc_flow_head_up_fwd(z.data_ptr(), params.data_ptr(), out.data_ptr(), up.data_ptr(), B, H, W,
+        rc = L.qpwc_flow_head_up_fwd(z.data_ptr(), params.data_ptr(), out.data_ptr(), up.data_ptr(),
+                                     up32.data_ptr() if up32 is not None else None, B, H, W,
                                      float(scale), float(up_scale), _DTYPES[z.dtype], _stream(z))
     _hip.check(rc)
+    if up32 is not None:
+        up._qpwc_f32 = up32
     return out, up
 
 

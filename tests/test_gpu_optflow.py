@@ -89,6 +89,10 @@ def test_flow_head_up_is_flow_head_plus_upsample(hw, dtype):
     flow1, up1 = ops.flow_head_up(z, params, scale, 2.0)
     assert torch.equal(flow1, flow)
     assert torch.equal(up1, up)
+    if dtype == torch.float16:   # the fp32 coordinates of the next level's warp, written by the same launch
+        assert torch.equal(up1._qpwc_f32, up.float())
+    else:
+        assert not hasattr(up1, "_qpwc_f32")
 
 
 @pytest.mark.parametrize("M,C,F", [(1024, 596, 128), (4096, 342, 128), (16384, 211, 128), (1000, 37, 16), (17, 64, 32),
