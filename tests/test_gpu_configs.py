@@ -300,7 +300,8 @@ def test_round4_launch_folding_switches_do_not_change_a_bit(dtype):
 
     ref = run()
     for attrs in ({"fuse_skip_copy": False}, {"fuse_flow_upsample": False}, {"prefill_skips": True},
-                  {"skip_copy_first": (3, 2)}, {"fuse_skip_copy": False, "prefill_skips": True}):
+                  {"skip_copy_first": (3, 2)}, {"fuse_skip_copy": False, "prefill_skips": True},
+                  {"capture_order": ("F0", "D0", "D1", "D2", "F1", "F2", "D3", "F3", "F4"), "dec_after_flow": {3: 2}}):
         got = run(**attrs)
         for lvl, (a, b) in enumerate(zip(got, ref)):
             assert torch.equal(a, b), "{}: level {} differs (max |diff| {:.3g})".format(
