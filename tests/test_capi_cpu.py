@@ -124,6 +124,52 @@ def test_argument_validation_of_the_next_rows_needs_no_gpu(hip_lib):
     assert L.qpwc_epe_multi_mixed_fwd(yt, (vp * 2)(q, q + 2), npix, planes, (ci * 2)(0, 1), 2, r, r, None) == _hip.E_ALIGN
 
 
+def test_argument_validation_of_the_round4_entry_points_needs_no_gpu(hip_lib):
+    """qpwc_upconv4x4s2_mish_cat_fwd / _f16, qpwc_flow_head_up_fwd, qpwc_pointwise_bias_fwd and the two query / probe entry points
+    reject bad arguments before any HIP call."""
+    from qpwcnet_amd import _hip
+    buf = (ctypes.c_float * 65536)()
+    base = ctypes.cast(buf, ctypes.c_void_p).value
+    base += (-base) % 16
+    p, q, r, t = base, base + 16384, base + 32768, base + 131072
+    L = hip_lib
+    F32, F16 = 0, 1
+    # UpConv + skip half of the concat: x (1,2,2,64) -> out (1,4,4,>=32), skip (1,4,4,16)
+    ok = dict(B=1, H=2, W=2, C=64, F=16)
+    def cat(x=p, w=q, b=q, skip=r, bs=256, rs=64, ps=16, out=t, ops=32, **kw):
+        a = dict(ok, **kw)
+        return L.qpwc_upconv4x4s2_mish_cat_fwd(x, w, b, skip, bs, rs, ps, out, a["B"], a["H"], a["W"], a["C"], a["F"], ops, None)
+    assert cat(skip=None) == _hip.E_NULL
+    assert cat(C=48) == _hip.E_SHAPE
+    assert cat(F=24) == _hip.E_SHAPE
+    assert cat(ops=16) == _hip.E_STRIDE            # no room for the skip half
+    assert cat(ps=8) == _hip.E_STRIDE              # skip pixels narrower than F
+    assert cat(rs=48) == _hip.E_STRIDE             # rows overlap
+    assert cat(ps=18, rs=72, bs=288) == _hip.E_STRIDE   # not a multiple of 4 elements
+    assert cat(skip=r + 4) == _hip.E_ALIGN
+    assert cat(out=r) == _hip.E_ALIAS              # out overlaps skip
+    assert L.qpwc_upconv4x4s2_mish_cat_f16_fwd(p, q, q, r + 2, 256, 64, 16, t, 1, 2, 2, 64, 16, 32, None) == _hip.E_ALIGN
+    # flow head + upsampling
+    assert L.qpwc_flow_head_up_fwd(p, q, r, None, None, 1, 2, 2, 1.0, 2.0, F32, None) == _hip.E_NULL
+    assert L.qpwc_flow_head_up_fwd(p, q, r, t, None, 1, 2, 2, 1.0, 2.0, 9, None) == _hip.E_DTYPE
+    assert L.qpwc_flow_head_up_fwd(p, q, r, t, None, 1, 0, 2, 1.0, 2.0, F32, None) == _hip.E_SHAPE
+    assert L.qpwc_flow_head_up_fwd(p, q, r, r, None, 1, 2, 2, 1.0, 2.0, F32, None) == _hip.E_ALIAS
+    assert L.qpwc_flow_head_up_fwd(p, q, r, t + 4, None, 1, 2, 2, 1.0, 2.0, F32, None) == _hip.E_ALIGN
+    assert L.qpwc_flow_head_up_fwd(p, q, r, t, t + 4096, 1, 2, 2, 1.0, 2.0, F32, None) == _hip.E_DTYPE   # fp32 copy of an fp32 flow
+    assert L.qpwc_flow_head_up_fwd(p, q, r, t, t, 1, 2, 2, 1.0, 2.0, F16, None) == _hip.E_ALIAS
+    # pointwise half of a split SeparableConv2D
+    assert L.qpwc_pointwise_bias_fwd(p, q, q, None, 16, 32, 16, None) == _hip.E_NULL
+    assert L.qpwc_pointwise_bias_fwd(p, q, q, r, 16, 32, 48, None) == _hip.E_SHAPE
+    assert L.qpwc_pointwise_bias_fwd(p, q, q, r, 0, 32, 16, None) == _hip.E_SHAPE
+    assert L.qpwc_pointwise_bias_fwd(p + 4, q, q, r, 16, 32, 16, None) == _hip.E_ALIGN
+    assert L.qpwc_pointwise_bias_fwd(p, q, q, p, 16, 32, 16, None) == _hip.E_ALIAS
+    # the kernel query answers without a device: refused arguments give the empty name
+    L.qpwc_cost_volume_kernel.restype = ctypes.c_char_p
+    assert L.qpwc_cost_volume_kernel(8, 128, 256, 32, 4, _hip.NHWC, F32, 84, 1).startswith(b"cost_volume_mfma_lds")
+    assert L.qpwc_cost_volume_kernel(8, 1, 32, 256, 4, _hip.NHWC, F32, 81, 1) == b""
+    assert L.qpwc_clock_probe(None, 4, 4, None) != 0
+
+
 def test_check_maps_codes_to_reference_exceptions(hip_lib):
     from qpwcnet_amd import _hip
     with pytest.raises(ValueError):
