@@ -459,7 +459,12 @@ class OptFlow(_Weighted):
         return t
 
     @staticmethod
-    def _fuse_layer(c_in, n_tiles):
+    def _fuse_layer(c_in, n_tiles, fp16=False):
+        # fp16 storage (round 4): the split form's multi-source depthwise kernel moves 2 bytes per lane and load (30 us at
+        # config 5's L0 / L1), so the fused kernel wins from 128 tiles on for up to 384 channels -- config 5's L1
+        # (342 channels, 128 tiles): step 1.615 -> 1.596 ms; its L0 (32 tiles) +-0, stays split
+        if fp16 and c_in <= 384 and n_tiles >= 128:
+            return True
         return c_in <= 128 or (c_in <= 256 and n_tiles >= 128) or n_tiles >= 256
 
     def __init__(self, params, prefix, filters=(128, 64, 32, 16), scale=None, *args, **kwargs):
@@ -515,7 +520,7 @@ class OptFlow(_Weighted):
             return True
         B, H, W = prv.shape[:3]
         self._prepare_hip()
-        return self._fuse_layer(self._dw[0].shape[0], B * ((H + 7) // 8) * ((W + 15) // 16))
+        return self._fuse_layer(self._dw[0].shape[0], B * ((H + 7) // 8) * ((W + 15) // 16), fp16=prv.dtype == torch.float16)
 
     def can_use_hip(self, sources):
         return (self.data_format == CHANNELS_LAST and self.filters[-1] == 16 and
@@ -547,7 +552,7 @@ class OptFlow(_Weighted):
             if not fp32 and (self._dw[i].shape[0] % 4 if i else not padded_cost):
                 return False    # fp16 (qpwc_sepconv3x3_f16_fwd): sources in 8-byte aligned runs of 4 channels
             if self.fused_sepconv is None:
-                return self._fuse_layer(self._dw[i].shape[0], n_tiles)
+                return self._fuse_layer(self._dw[i].shape[0], n_tiles, fp16=not fp32)
             return bool(self.fused_sepconv)
 
         use_tail = (fp32 and self.filters == (128, 64, 32, 16) and B * H * W <= self.tail_max_pixels and

@@ -238,6 +238,7 @@ def test_optflow_layer_fusion_rule():
     assert f(211, 128) and not f(211, 64)               # first layer of L2 at B=8 / fewer tiles
     assert not f(339, 32) and not f(593, 8)             # wide first layers of L1 / L0 stay depthwise + GEMM
     assert f(147, 512) and f(115, 2048) and f(593, 256)
+    assert f(339, 128, fp16=True) and not f(339, 128) and not f(593, 32, fp16=True)   # config 5's L1 fused, its L0 split
     assert non_layers.OptFlow.tail_max_pixels == 16384  # one-launch tail at L0-L2 for B=8, 256x512
 
 
