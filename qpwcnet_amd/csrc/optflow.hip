@@ -127,8 +127,7 @@ struct VecIo<__half, 4> {
 };
 
 template <typename T, int VEC, bool ACT>
-__global__ __launch_bounds__(256) void dwconv3x3_vec_kernel(const T* __restrict__ in, int64_t ps,
-                                                            const float* __restrict__ weight,
+__global__ __launch_bounds__(256) void dwconv3x3_vec_kernel(DwSrc src, const float* __restrict__ weight,
                                                             T* __restrict__ out, int H, int W, int C,
                                                             int strips, int wq, int rows) {
     const int cv = C / VEC;
@@ -139,7 +138,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_vec_kernel(const T* __restrict_
     const int x0 = xq * kDwPx;
     const int strip = blockIdx.y % strips, b = blockIdx.y / strips;
     const int y0 = strip * rows;
-    const T* p = in + (int64_t)b * H * W * ps + c;
+    // (round 4) up to three sources, each a multiple of VEC channels in VEC-element aligned pixels: the lane's VEC channels
+    // lie in one of them (config 5's level-0 layer: 84 + 256 + 256 channels, 30 us on the one-channel-per-lane kernel)
+    const DwPick pk = dwsrc_pick(src, c, C);
+    const int64_t ps = pk.ps;
+    const T* p = (const T*)pk.p + (int64_t)b * H * W * ps + pk.cc;
 
     float w[9][VEC];
 #pragma unroll
@@ -219,11 +222,11 @@ static void dwconv_vec_dispatch(const DwSrc& d, int act, const void* weight, voi
     const int64_t rowthreads = (int64_t)wq * (C / VEC);
     const dim3 grid((unsigned)((rowthreads + 255) / 256), (unsigned)(strips * B));
     if (act)
-        hipLaunchKernelGGL((dwconv3x3_vec_kernel<T, VEC, true>), grid, dim3(256), 0, s, (const T*)d.ptr[0],
-                           d.stride[0], (const float*)weight, (T*)out, H, W, C, strips, wq, rows);
+        hipLaunchKernelGGL((dwconv3x3_vec_kernel<T, VEC, true>), grid, dim3(256), 0, s, d,
+                           (const float*)weight, (T*)out, H, W, C, strips, wq, rows);
     else
-        hipLaunchKernelGGL((dwconv3x3_vec_kernel<T, VEC, false>), grid, dim3(256), 0, s, (const T*)d.ptr[0],
-                           d.stride[0], (const float*)weight, (T*)out, H, W, C, strips, wq, rows);
+        hipLaunchKernelGGL((dwconv3x3_vec_kernel<T, VEC, false>), grid, dim3(256), 0, s, d,
+                           (const float*)weight, (T*)out, H, W, C, strips, wq, rows);
 }
 
 template <typename T>
@@ -255,9 +258,9 @@ int dwconv3x3_launch(const void* const* srcs, const int* chans, const int64_t* s
     const int wq = (W + kDwPx - 1) / kDwPx;
     // fp16 storage, single aligned source: 4 channels per lane (measured +3 % on the fp16 step;
     // the fp32 analogue with 2 channels per lane measured 1.5 % slower than one per lane)
-    const bool vec_ok = dtype == QPWC_F16 && n_src == 1 && d.stride[0] % 4 == 0 && C % 4 == 0 &&
-                        reinterpret_cast<uintptr_t>(d.ptr[0]) % 8 == 0 &&
-                        reinterpret_cast<uintptr_t>(out) % 8 == 0;
+    bool vec_ok = dtype == QPWC_F16 && C % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
+    for (int i = 0; i < n_src; ++i)      // every source: a multiple of 4 channels in 8-byte aligned pixels
+        vec_ok = vec_ok && d.ch[i] % 4 == 0 && d.stride[i] % 4 == 0 && reinterpret_cast<uintptr_t>(d.ptr[i]) % 8 == 0;
     if (vec_ok) {
         dwconv_vec_dispatch<__half, 4>(d, act, weight, out, B, H, W, C, strips, wq, rows, s);
         return check_launch("dwconv3x3_vec_kernel");

@@ -198,6 +198,16 @@ def test_optflow_pieces_fp16_storage():
         out = ops.dwconv3x3([s.to(DEV) for s in srcs], w.to(DEV), mish_on_load=act)
         assert out.dtype == torch.float16
         torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+    # every source a multiple of 4 channels in aligned pixels (config 5's level-0 layer: 84 + 256 + 256): the kernel with
+    # 4 channels per lane over a virtual concat (round 4) -- same bound, and the same bits as one dense source
+    srcs4 = [_rand(rng, 3, 9, 17, c).half() for c in (84, 256, 256)]
+    w4 = _rand(rng, 596, 1, 3, 3)
+    for act in (False, True):
+        ref = torch_ref.depthwise3x3([s.float() for s in srcs4], w4, act)
+        out = ops.dwconv3x3([s.to(DEV) for s in srcs4], w4.to(DEV), mish_on_load=act)
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+        one = ops.dwconv3x3([torch.cat(srcs4, dim=3).to(DEV)], w4.to(DEV), mish_on_load=act)
+        assert torch.equal(out, one)
     x = (_rand(rng, 2, 9, 11, 16) * 3).half()
     b = _rand(rng, 16)
     out = ops.bias_mish_(x.to(DEV).clone(), b.to(DEV)).float().cpu()
