@@ -104,6 +104,9 @@ __device__ __forceinline__ int ec_slot(int q, int hp) {
 // it waited with vmcnt(7), (6), .. (0) through the trip's eight groups of matrix instructions -- i.e. for the requests that
 // were issued a moment ago at the top of THIS trip, one by one, instead of for the ones issued a whole trip earlier
 // (vmcnt is a counter of outstanding requests, in order): an L2 round trip exposed at the top of every 32-channel block.
+#ifndef QPWC_UPCONV16_NFB_MIN_WGS
+#define QPWC_UPCONV16_NFB_MIN_WGS 512   // fp16 transposed convolution: see nfb in upconv_f16_launch_t (1 << 30 = one block per workgroup)
+#endif
 #ifndef QPWC_UPCONV256_TH
 #define QPWC_UPCONV256_TH 2   // input rows per workgroup of the 256- / 128-channel transposed convolutions (A/B, round 4)
 #endif
@@ -1183,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
                                                                       const float* __restrict__ bias,
                                                                       __half* __restrict__ out, int H, int W, int F,
                                                                       int out_pixel_stride, int tiles_x, int tiles_y,
-                                                                      int n_tiles, UpSkip skip) {
+                                                                      int n_tiles, UpSkip skip, int nfb) {
     constexpr int NQ = C / 8, NKB = C / 32;
     constexpr int HH = TH + 2, NH = HH * kEcHW;
     constexpr int NST = (NH * NQ + 255) / 256;
@@ -1192,11 +1195,13 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int py = wave >> 1, px = wave & 1;
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int fblk = blockIdx.x / n_tiles;
+    // Round 4: a workgroup stages its halo tile ONCE and walks nfb blocks of 16 outputs with it (fp16: the 16-cycle matrix
+    // instructions no longer hide F / 16 workgroups re-staging the same tile; grid = tiles x F / 16 / nfb)
+    const int fblk0 = (blockIdx.x / n_tiles) * nfb;
     const int tile = xcd_swizzle(blockIdx.x % n_tiles, n_tiles);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int X0 = tx * kEcTW, Y0 = ty * TH;
-    const int fo = 16 * fblk;
+    int fo = 16 * fblk0;
     const __half* xb = x + (int64_t)b * H * W * C;
     {
         uint4 st[NST];
@@ -1222,8 +1227,6 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
     const int kpos[4] = {ky0 * 4 + kx0, ky0 * 4 + kx1, ky1 * 4 + kx0, ky1 * 4 + kx1};
     const int offy[4] = {0, 0, dy1, dy1}, offx[4] = {0, dx1, 0, dx1};
     f32x4e acc[TH];
-#pragma unroll
-    for (int m = 0; m < TH; ++m) acc[m] = f32x4e{0.f, 0.f, 0.f, 0.f};
     f16x8e wv[4], wn[4];
     auto load_w = [&](f16x8e (&w)[4], int kb) {
 #pragma unroll
@@ -1263,6 +1266,12 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
             }
 #endif
     };
+#pragma unroll 1
+    for (int fb = 0; fb < nfb; ++fb) {
+    fo = 16 * (fblk0 + fb);
+    if (fb > 0) load_w(wv, 0);     // (the first block's weights went out before the barrier)
+#pragma unroll
+    for (int m = 0; m < TH; ++m) acc[m] = f32x4e{0.f, 0.f, 0.f, 0.f};
 #if QPWC_W_NEXT_ALWAYS_F16
     {
         int kb = 0;
@@ -1315,6 +1324,7 @@ __global__ __launch_bounds__(256, 2) void upconv4x4s2_mish_f16_kernel(const __ha
             if (sk != nullptr) *reinterpret_cast<f16x4e*>(op + F) = sv[m];
         }
     }
+    }   // fb
 }
 
 template <int C, int TH>
@@ -1326,9 +1336,12 @@ static int upconv_f16_launch_t(const void* x, const void* weight, const void* bi
         set_error("upconv4x4s2_mish_f16: too many tiles");
         return QPWC_E_SHAPE;
     }
-    hipLaunchKernelGGL((upconv4x4s2_mish_f16_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16))), dim3(256), 0, s,
+    // output blocks per workgroup: as many as leave the launch QPWC_UPCONV16_NFB_MIN_WGS workgroups (two per CU)
+    int nfb = 1;
+    while (nfb * 2 <= F / 16 && (F / 16) % (nfb * 2) == 0 && n_tiles * (F / 16) / (nfb * 2) >= QPWC_UPCONV16_NFB_MIN_WGS) nfb *= 2;
+    hipLaunchKernelGGL((upconv4x4s2_mish_f16_kernel<C, TH>), dim3((unsigned)(n_tiles * (F / 16) / nfb)), dim3(256), 0, s,
                        (const __half*)x, (const __half*)weight, (const float*)bias, (__half*)out, H, W, F,
-                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles, skip);
+                       out_pixel_stride, tiles_x, tiles_y, (int)n_tiles, skip, nfb);
     return check_launch("upconv4x4s2_mish_f16_kernel");
 }
 
