@@ -447,6 +447,7 @@ class OptFlow(_Weighted):
     # with 16 pixels per workgroup every workgroup streams the whole (F, C) weight matrix from L2.  Off; the two library
     # GEMMs of L0 / L1 stay the only library launches of a step.
     own_pointwise = False
+    cost84_for_split_fp16 = False   # see wants_cost84: measured +-0 on config 5 (three interleaved pairs of one call): off
     fuse_upsample = False   # set by QpwcNet on its own blocks: flow head + the x2 upsampling of the flow in one launch
     # ... where the two launches are bound by their start-up, not by their work (the fused one recomputes the tile's rim):
     # config 2 (B=8: L3 65 k, L4 262 k pixels) 1.120 vs 1.124 ms/step with it, config 5 (B=32: L4 1 M pixels) 1.626 vs 1.617
@@ -509,14 +510,18 @@ class OptFlow(_Weighted):
                                     self.BN_EPS, self.p("flow.weight"))
         self._hip_ready = True
 
-    def wants_cost84(self, prv):
-        """Flow/UpFlow ask: should the cost volume be produced as 84 channels (81 + 3 zero pads)?  Only
-        a FUSED first layer profits (16-byte loads of all three sources); where it stays split (coarse
-        levels) the dense 81-channel volume avoids the extra pad-zeroing launch."""
+    def wants_cost84(self, prv, other_channels=None):
+        """Flow/UpFlow ask: should the cost volume be produced as 84 channels (81 + 3 zero pads)?  A FUSED first
+        layer profits (16-byte loads of all three sources) -- and, for fp16 storage, a SPLIT one whose other sources hold
+        multiples of 4 channels (`other_channels`: the coarsest level's [cost | prv | nxt]): its depthwise half then runs
+        on the 4-channels-per-lane kernel (round 4).  Elsewhere the dense 81-channel volume avoids the pad-zeroing."""
         if not (self.data_format == CHANNELS_LAST and prv.is_cuda and prv.dtype in (torch.float32, torch.float16) and
                 prv.shape[3] % 4 == 0 and self.filters[-1] == 16 and self.fused_sepconv is not False):
             return False
         if self.fused_sepconv is True:
+            return True
+        if self.cost84_for_split_fp16 and prv.dtype == torch.float16 and other_channels is not None and \
+                all(c % 4 == 0 for c in other_channels):
             return True
         B, H, W = prv.shape[:3]
         self._prepare_hip()
@@ -643,7 +648,7 @@ class Flow(_Weighted):
 
     def __call__(self, inputs):
         prv, nxt = inputs
-        if self.hip_optflow and self.flow.wants_cost84(prv):
+        if self.hip_optflow and self.flow.wants_cost84(prv, other_channels=(prv.shape[-1], nxt.shape[-1])):
             cost = _cost84(prv, nxt, self.cost_volume.search_range)
             return self.flow.from_sources((cost, prv, nxt))
         cost = self.cost_volume((prv, nxt))
