@@ -1365,7 +1365,11 @@ int upconv4x4s2_mish_f16_launch(const void* x, const void* weight, const void* b
 // K = 27: one v_mfma_f32_16x16x4_f32 per tap with k-slot g = input channel (slot 3 = 0).
 // Workgroup = 8 x 16 output pixels of BOTH frames (they share the staged 17 x 33 x 6 input patch);
 // wave w -> frame w >> 1, output rows 4 (w & 1) .. + 3.   weight: [9 taps][16 out][4] fp32 (slot 3 = 0).
-constexpr int kFcIH = 2 * kEcTH + 1, kFcIW = 2 * kEcTW + 1;   // 17 x 33 input pixels
+#ifndef QPWC_FC_ROWS
+#define QPWC_FC_ROWS 4     // output rows per wave of the first encoder layer: the workgroup's tile is 2 QPWC_FC_ROWS x 16 (A/B, round 4)
+#endif
+constexpr int kFcTR = QPWC_FC_ROWS, kFcTH = 2 * kFcTR;
+constexpr int kFcIH = 2 * kFcTH + 1, kFcIW = 2 * kEcTW + 1;   // 17 x 33 input pixels at four rows per wave
 
 // T = __half: the fp16-storage form (BASELINE configs[4]) -- pairs and out fp16, the patch converted to fp32 on its
 // way into LDS (exact), weights / bias / arithmetic as for fp32, one rounding at the store.
@@ -1381,7 +1385,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const T* __rest
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int X0 = tx * kEcTW, Y0 = ty * kEcTH;           // output coordinates
+    const int X0 = tx * kEcTW, Y0 = ty * kFcTH;           // output coordinates
     const int Ho = H / 2, Wo = W / 2;
     const T* xb = x + (int64_t)b * H * W * 6;
     // ---- stage the input patch: rows 2 Y0 .. + 16, columns 2 X0 .. + 32, 6 channels (pieces of 2 channels) ----
@@ -1422,17 +1426,17 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const T* __rest
 
     const int f = wave >> 1;
     T* ob = out + (int64_t)(f * B + b) * Ho * Wo * 16;
-    f32x4e acc[4];
+    f32x4e acc[kFcTR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < kFcTR; ++r) acc[r] = f32x4e{0.f, 0.f, 0.f, 0.f};
     // (round 4) a tap's four operand reads are issued together, one tap ahead of the matrix instructions that use them: as
     // the compiler placed them every matrix instruction waited for its own ds_read_b32
-    float vb[2][4];
-    auto read_tap = [&](float (&v)[4], int k) __attribute__((always_inline)) {
+    float vb[2][kFcTR];
+    auto read_tap = [&](float (&v)[kFcTR], int k) __attribute__((always_inline)) {
         const int ky = k / 3, kx = k - 3 * ky;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oy = 4 * (wave & 1) + r;
+        for (int r = 0; r < kFcTR; ++r) {
+            const int oy = kFcTR * (wave & 1) + r;
             v[r] = in_s[((2 * oy + ky) * kFcIW + 2 * n + kx) * 6 + 3 * f + (g < 3 ? g : 2)];   // (no branch around the read; k-slot 3 is zeroed at its use)
         }
     };
@@ -1442,13 +1446,13 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const T* __rest
         if (k + 1 < 9) read_tap(vb[(k + 1) & 1], k + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)   // 4 independent accumulators (output rows) per tap
+        for (int r = 0; r < kFcTR; ++r)   // independent accumulators (output rows) per tap
             acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[k], g < 3 ? vb[k & 1][r] : 0.0f, acc[r], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int gy = Y0 + 4 * (wave & 1) + r, gx = X0 + n;
+    for (int r = 0; r < kFcTR; ++r) {
+        const int gy = Y0 + kFcTR * (wave & 1) + r, gx = X0 + n;
         if (gy < Ho && gx < Wo)
             st4q(ob + ((int64_t)gy * Wo + gx) * 16 + 4 * g,
                  make_float4(enc_mishf(acc[r][0] + bq.x), enc_mishf(acc[r][1] + bq.y), enc_mishf(acc[r][2] + bq.z),
@@ -1458,7 +1462,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_mish_kernel(const T* __rest
 
 int first_conv_mish_launch(const void* x, const void* weight, const void* bias, void* out, int B, int H, int W,
                            int layout, int dtype, hipStream_t s) {
-    const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + kEcTH - 1) / kEcTH;
+    const int tiles_x = (W / 2 + kEcTW - 1) / kEcTW, tiles_y = (H / 2 + kFcTH - 1) / kFcTH;
     const int64_t nblk = (int64_t)tiles_x * tiles_y * B;
     if (nblk > INT32_MAX) {
         set_error("first_conv_mish: too many tiles");
